@@ -1,0 +1,368 @@
+"""Generate the golden vectors under tests/golden/ by importing the REFERENCE (read-only, /root/reference).
+
+Run only in the build container (the reference does not exist on the GPU box):
+
+    python tests/golden/make_goldens.py [--only G5] [--skip-xl]
+
+The reference ships no tests, so these vectors -- inputs plus the reference's own outputs -- are what pins
+the oracle (oracle/) and, through it, the HIP path.  Only DATA is written (npz of inputs/weights/outputs);
+no reference source is copied.  Import shims follow SURVEY.md App. B.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+
+
+def load_reference():
+    import transformers.modeling_utils as mu
+
+    mu.PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)  # shim 1
+    np.int = int  # shim 2
+    pkg = types.ModuleType("model")
+    pkg.__path__ = [os.path.join(REF, "model")]
+    sys.modules["model"] = pkg
+
+    def _load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    adapter = _load("model.adapter", os.path.join(REF, "model/adapter.py"))
+    deberta = _load("model.deberta", os.path.join(REF, "model/deberta.py"))
+    deberta.BaseModelOutput = dataclasses.dataclass(deberta.BaseModelOutput)  # shim 4
+    deberta._softmax_backward_data = lambda g, o, dim, t: torch._softmax_backward_data(g, o, dim, t.dtype)  # shim 5
+    misc = _load("ref_util_misc", os.path.join(REF, "util/misc.py"))
+    return adapter, deberta, misc
+
+
+def ref_config(cfg):
+    from transformers import DebertaV2Config
+
+    return DebertaV2Config(
+        vocab_size=cfg.vocab_size,
+        hidden_size=cfg.hidden_size,
+        num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads,
+        intermediate_size=cfg.intermediate_size,
+        max_position_embeddings=cfg.max_position_embeddings,
+        type_vocab_size=0,
+        hidden_act="gelu",
+        hidden_dropout_prob=0.1,
+        attention_probs_dropout_prob=0.1,
+        layer_norm_eps=cfg.layer_norm_eps,
+        relative_attention=True,
+        position_buckets=cfg.position_buckets,
+        max_relative_positions=cfg.max_relative_positions,
+        pos_att_type=["p2c", "c2p"],
+        norm_rel_ebd="layer_norm",
+        share_att_key=True,
+        position_biased_input=False,
+        conv_kernel_size=cfg.conv_kernel_size,
+        conv_act="gelu",
+        pad_token_id=cfg.pad_token_id,
+        attention_head_size=cfg.hidden_size // cfg.num_attention_heads,
+    )
+
+
+def build_ref_model(deberta, cfg, P):
+    m = deberta.DebertaV2ForMaskedLM(
+        ref_config(cfg),
+        max_feats=cfg.max_feats,
+        features_dim=cfg.features_dim,
+        ds_factor_attn=cfg.ds_factor_attn,
+        ds_factor_ff=cfg.ds_factor_ff,
+        n_ans=cfg.n_ans,
+    )
+    sd = m.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    extra = [k for k in sd if k not in P and "position_ids" not in k and "decoder" not in k]
+    assert not extra, extra
+    m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=False)
+    m.eval()
+    return m
+
+
+def synth_batch(cfg, B, L, seed, ragged=True, lo_id=5):
+    """Seeded synthetic batch: fp16-rounded N(0,1) features, ragged lengths, 15% labels."""
+    g = torch.Generator().manual_seed(seed)
+    T = cfg.max_feats
+    video = torch.randn(B, T, cfg.features_dim, generator=g).half().float()
+    if ragged:
+        vlen = torch.randint(1, T + 1, (B,), generator=g)
+        vlen[0] = T
+        tlen = torch.randint(max(2, L // 8), L + 1, (B,), generator=g)
+        tlen[-1] = L
+    else:
+        vlen = torch.full((B,), T)
+        tlen = torch.full((B,), L)
+    ids = torch.randint(lo_id, cfg.vocab_size, (B, L), generator=g)
+    pos = torch.arange(L)[None]
+    amask = (pos < tlen[:, None]).long()
+    ids = ids * amask  # pad id 0
+    vmask = (torch.arange(T)[None] < vlen[:, None]).long()
+    sel = (torch.rand(B, L, generator=g) < 0.15) & amask.bool()
+    sel[:, 1] = True  # at least one label per row
+    labels = torch.where(sel, ids, torch.full_like(ids, -100))
+    return dict(video=video, video_mask=vmask, input_ids=ids, attention_mask=amask, labels=labels)
+
+
+def npz(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KB)")
+
+
+# ----------------------------------------------------------------------------------------------
+def g1_adapter(adapter_mod):
+    torch.manual_seed(11)
+    a = adapter_mod.Adapter(8, 128, dropout=0.1).eval()
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(torch.randn(p.shape) * 0.05)
+    x = torch.randn(2, 7, 128)
+    y = a(x)
+    npz("G1_adapter", x=x, y=y, **{"w." + k: v for k, v in a.state_dict().items()})
+
+
+def g2_relpos(deberta):
+    out = {}
+    for S in (1, 2, 74, 129, 266, 512):
+        r = deberta.build_relative_position(S, S, bucket_size=256, max_position=512)[0].numpy()
+        assert (r == r[:, :1] * 0 + r).all()
+        # Toeplitz: store first column (delta >= 0) and first row (delta <= 0) + a checksum of the full table
+        out[f"col_{S}"] = r[:, 0].copy()
+        out[f"row_{S}"] = r[0, :].copy()
+        out[f"sum_{S}"] = np.array([int(np.abs(r).sum()), int((r * np.arange(S)[None, :]).sum())], dtype=np.int64)
+        i, j = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+        d = i - j
+        tv = np.where(d >= 0, r[:, 0][np.abs(d)], r[0, :][np.abs(d)])
+        assert (tv == r).all(), "reference table is not Toeplitz"
+    npz("G2_relpos", **out)
+
+
+def _tiny_cfg(**kw):
+    from oracle.deberta_oracle import OracleConfig
+
+    base = dict(vocab_size=512, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=512,
+                features_dim=32, max_feats=10)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+def g3_attention(deberta):
+    """DisentangledSelfAttention eval, d=64, 2 heads, S=37 and 266, padded rows, with and without query_states."""
+    from oracle.deberta_oracle import synth_params, relative_position
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    enc = m.deberta.encoder
+    att = enc.layer[1].attention.self
+    out = {}
+    for S in (37, 266):
+        g = torch.Generator().manual_seed(100 + S)
+        B = 2
+        hidden = torch.randn(B, S, cfg.hidden_size, generator=g)
+        qs = torch.randn(B, S, cfg.hidden_size, generator=g)
+        mask = torch.ones(B, S, dtype=torch.long)
+        mask[0, S - 5:] = 0
+        mask[1, 3:6] = 0
+        with torch.no_grad():
+            m4 = enc.get_attention_mask(mask)
+            rel = enc.get_rel_pos(hidden)
+            remb = enc.get_rel_embedding()
+            y0 = att(hidden, m4, False, query_states=None, relative_pos=rel, rel_embeddings=remb)
+            y1 = att(hidden, m4, False, query_states=qs, relative_pos=None, rel_embeddings=remb)
+        out.update({f"hidden_{S}": hidden, f"qs_{S}": qs, f"mask_{S}": mask, f"ctx_{S}": y0, f"ctxq_{S}": y1})
+    out["rel_emb"] = remb
+    npz("G3_attention", seed=np.array([3]), **out)
+
+
+def g4_layer_conv(deberta):
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=4, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    enc = m.deberta.encoder
+    g = torch.Generator().manual_seed(44)
+    B, S = 2, 45
+    hidden = torch.randn(B, S, cfg.hidden_size, generator=g)
+    qs = torch.randn(B, S, cfg.hidden_size, generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[0, 30:] = 0
+    with torch.no_grad():
+        m4 = enc.get_attention_mask(mask)
+        rel = enc.get_rel_pos(hidden)
+        remb = enc.get_rel_embedding()
+        y_layer = enc.layer[2](hidden, m4, False, query_states=None, relative_pos=rel, rel_embeddings=remb)
+        y_layer_q = enc.layer[2](hidden, m4, False, query_states=qs, relative_pos=None, rel_embeddings=remb)
+        y_conv = enc.conv(hidden, qs, mask)
+    npz("G4_layer_conv", seed=np.array([4]), hidden=hidden, qs=qs, mask=mask, y_layer=y_layer, y_layer_q=y_layer_q,
+        y_conv=y_conv)
+
+
+def g5_tiny_model(deberta):
+    """Tiny full model eval: logits, loss, all trainable grads, hidden states."""
+    from oracle.deberta_oracle import synth_params, is_trainable
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    batch = synth_batch(cfg, B=3, L=27, seed=55)
+    out = m(**batch)
+    out.loss.backward()
+    grads = {}
+    names_trainable = []
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            names_trainable.append(n)
+            assert p.grad is not None, n
+            grads["grad." + n] = p.grad
+    assert sorted(names_trainable) == sorted(k for k in P if is_trainable(k)), "freeze policy mismatch"
+    hs = torch.stack(out.hidden_states, 0)
+    npz("G5_tiny_model", seed=np.array([5]), logits=out.logits, loss=out.loss, hidden_states=hs,
+        **{"in." + k: v for k, v in batch.items()}, **grads)
+    # same inputs, no video / no labels (text-only branch)
+    with torch.no_grad():
+        o2 = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"])
+    npz("G5b_tiny_textonly", logits=o2.logits)
+
+
+def g6_xlarge(deberta):
+    """True xlarge dims, weights from seed recipe (not stored), B=2 S=266 eval: logits slice + checksum + loss."""
+    from oracle.deberta_oracle import OracleConfig, synth_params
+
+    cfg = OracleConfig()
+    P = synth_params(cfg, seed=0)
+    m = build_ref_model(deberta, cfg, P)
+    batch = synth_batch(cfg, B=2, L=256, seed=66)
+    with torch.no_grad():
+        out = m(**batch)
+    lg = out.logits
+    npz("G6_xlarge", seed=np.array([0]), batch_seed=np.array([66]), loss=out.loss,
+        logits_slice=lg[:, ::19, ::997].contiguous(), logits_sum=lg.double().sum(), logits_abs_sum=lg.double().abs().sum(),
+        logits_row0=lg[0, 12, :2048].contiguous(), argmax=lg.argmax(-1),
+        top5=lg.topk(5, -1).indices[:, ::7].contiguous())
+
+
+def g7_misc(misc):
+    class Tok:
+        mask_token = "[MASK]"
+        _pad_token = "[PAD]"
+        pad_token_id = 0
+
+        def __len__(self):
+            return 1000
+
+        def get_special_tokens_mask(self, val, already_has_special_tokens=True):
+            return [1 if v in (1, 2) else 0 for v in val]
+
+        def convert_tokens_to_ids(self, t):
+            return 4
+
+    out = {}
+    for seed in (0, 1):
+        g = torch.Generator().manual_seed(700 + seed)
+        ids = torch.randint(5, 1000, (4, 33), generator=g)
+        ids[:, 0] = 1
+        lens = torch.tensor([33, 20, 9, 2])
+        for b in range(4):
+            ids[b, lens[b] - 1] = 2
+            ids[b, lens[b]:] = 0
+        torch.manual_seed(seed)
+        inp, lab = misc.mask_tokens(ids.clone(), Tok(), 0.15)
+        out[f"ids_{seed}"] = ids
+        out[f"inputs_{seed}"] = inp
+        out[f"labels_{seed}"] = lab
+    vl = torch.tensor([10, 3, 0, 7])
+    out["video_len"] = vl
+    out["get_mask"] = misc.get_mask(vl, 10)
+
+    class A:
+        pass
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+
+    lrs = []
+    for sched in ("", "linear_with_warmup"):
+        a = A()
+        a.lr, a.schedule, a.fraction_warmup_steps = 3e-4, sched, 0.1
+        for step in (0, 1, 9, 10, 11, 50, 99, 100):
+            o = Opt()
+            misc.adjust_learning_rate(o, step, 100, a)
+            lrs.append(o.param_groups[0]["lr"])
+    out["lrs"] = np.array(lrs, dtype=np.float64)
+    npz("G7_misc", **out)
+
+
+def g9_answers(deberta):
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg(n_ans=50)
+    P = synth_params(cfg, seed=9, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    g = torch.Generator().manual_seed(99)
+    a2tok = torch.randint(5, cfg.vocab_size, (50, 5), generator=g)
+    alen = torch.randint(1, 6, (50,), generator=g)
+    a2tok = a2tok * (torch.arange(5)[None] < alen[:, None])
+    m.set_answer_embeddings(a2tok)
+    batch = synth_batch(cfg, B=3, L=27, seed=91)
+    batch.pop("labels")
+    with torch.no_grad():
+        out = m(**batch)
+    lg = out.logits
+    npz("G9_answers", seed=np.array([9]), a2tok=a2tok, answer_embeddings=m.answer_embeddings.weight,
+        answer_bias=m.answer_bias, logits=lg, top10=lg.softmax(-1).topk(10, -1).indices,
+        **{"in." + k: v for k, v in batch.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--skip-xl", action="store_true")
+    args = ap.parse_args()
+    adapter_mod, deberta, misc = load_reference()
+    torch.set_grad_enabled(True)
+    jobs = {
+        "G1": lambda: g1_adapter(adapter_mod),
+        "G2": lambda: g2_relpos(deberta),
+        "G3": lambda: g3_attention(deberta),
+        "G4": lambda: g4_layer_conv(deberta),
+        "G5": lambda: g5_tiny_model(deberta),
+        "G6": lambda: g6_xlarge(deberta),
+        "G7": lambda: g7_misc(misc),
+        "G9": lambda: g9_answers(deberta),
+    }
+    for k, fn in jobs.items():
+        if args.only and k not in args.only.split(","):
+            continue
+        if k == "G6" and args.skip_xl:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()

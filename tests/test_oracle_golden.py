@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the reference (tests/golden/).
+
+CPU only.  Tolerances: integer tables bit-exact; fp32 activations <= 2e-5 max-abs (same ATen kernels,
+different association order); grads <= 1e-4 relative to their max.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import deberta_oracle as O
+from oracle import misc_oracle as MO
+from tests.golden.make_goldens import _tiny_cfg, synth_batch
+
+
+def maxabs(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def test_g1_adapter(golden):
+    g = golden("G1_adapter")
+    P = {"a." + k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    y = O.adapter(g["x"], P, "a")
+    assert maxabs(y, g["y"]) < 1e-6
+
+
+@pytest.mark.parametrize("S", [1, 2, 74, 129, 266, 512])
+def test_g2_relpos_bit_exact(golden, S):
+    g = golden("G2_relpos")
+    r = O.relative_position(S, S, 256, 512)
+    assert r.dtype == np.int64
+    assert (r[:, 0] == g[f"col_{S}"].numpy()).all()
+    assert (r[0, :] == g[f"row_{S}"].numpy()).all()
+    chk = np.array([int(np.abs(r).sum()), int((r * np.arange(S)[None, :]).sum())])
+    assert (chk == g[f"sum_{S}"].numpy()).all()
+    # antisymmetry => the p2c index equals the c2p index; Toeplitz vector form matches the table
+    cfg = O.OracleConfig()
+    idx = O.rel_index_by_delta(S, cfg)
+    i, j = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    c2p = np.clip(r + 256, 0, 511)
+    p2c_t = np.clip(-r.T + 256, 0, 511)
+    assert (c2p == p2c_t).all()
+    assert (idx[i - j + S - 1] == c2p).all()
+
+
+@pytest.mark.parametrize("S", [37, 266])
+def test_g3_attention(golden, S):
+    g = golden("G3_attention")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1)
+    hidden, qs, mask = g[f"hidden_{S}"], g[f"qs_{S}"], g[f"mask_{S}"]
+    m = mask.float()
+    mask4d = (m[:, None, None, :] * m[:, None, :, None]).to(torch.uint8)
+    rel = O.relative_position(S, S, 256, 512)
+    remb = O._ln(P["deberta.encoder.rel_embeddings.weight"], P, "deberta.encoder.LayerNorm", cfg.layer_norm_eps)
+    assert maxabs(remb, g["rel_emb"]) < 1e-5
+    pre = "deberta.encoder.layer.1.attention.self"
+    y0 = O.disentangled_attention(hidden, mask4d, rel, remb, P, pre, cfg)
+    y1 = O.disentangled_attention(hidden, mask4d, rel, remb, P, pre, cfg, query_states=qs)
+    assert maxabs(y0, g[f"ctx_{S}"]) < 2e-5
+    assert maxabs(y1, g[f"ctxq_{S}"]) < 2e-5
+    # padded query rows are exactly zero (XSoftmax turns the all -inf row into 0)
+    assert (y0[0, S - 5:] == 0).all()
+
+
+def test_g4_layer_conv(golden):
+    g = golden("G4_layer_conv")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=4, std=0.05, ln_jitter=0.1)
+    hidden, qs, mask = g["hidden"], g["qs"], g["mask"]
+    S = hidden.shape[1]
+    m = mask.float()
+    mask4d = (m[:, None, None, :] * m[:, None, :, None]).to(torch.uint8)
+    rel = O.relative_position(S, S, 256, 512)
+    remb = O._ln(P["deberta.encoder.rel_embeddings.weight"], P, "deberta.encoder.LayerNorm", cfg.layer_norm_eps)
+    pre = "deberta.encoder.layer.2"
+    assert maxabs(O.layer(hidden, mask4d, rel, remb, P, pre, cfg), g["y_layer"]) < 2e-5
+    assert maxabs(O.layer(hidden, mask4d, rel, remb, P, pre, cfg, query_states=qs), g["y_layer_q"]) < 2e-5
+    assert maxabs(O.conv_layer(hidden, qs, mask, P, cfg), g["y_conv"]) < 2e-5
+
+
+def test_g5_tiny_model_logits_loss_grads(golden):
+    g = golden("G5_tiny_model")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    regen = synth_batch(cfg, B=3, L=27, seed=55)
+    for k in batch:
+        assert torch.equal(batch[k], regen[k]), k  # the seeded generator recipe is reproducible
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    out = O.forward(P, cfg, return_hidden=True, **batch)
+    assert maxabs(out["logits"], g["logits"]) < 5e-5
+    assert abs(out["loss"].item() - g["loss"].item()) < 1e-5
+    hs = torch.stack(out["hidden_states"], 0)
+    assert maxabs(hs, g["hidden_states"]) < 2e-5
+    out["loss"].backward()
+    n = 0
+    for k, v in P.items():
+        if O.is_trainable(k):
+            ref = g["grad." + k]
+            tol = 1e-4 * max(ref.abs().max().item(), 1e-3)
+            assert maxabs(v.grad, ref) < tol, k
+            n += 1
+    assert n == len([k for k in g if k.startswith("grad.")])
+    # skipping the dead in-encoder pass of the last layer changes neither logits nor loss
+    out2 = O.forward(P, cfg, return_hidden=False, **batch)
+    assert torch.equal(out2["logits"], out["logits"])
+
+
+def test_g5b_text_only(golden):
+    g5 = golden("G5_tiny_model")
+    gb = golden("G5b_tiny_textonly")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    with torch.no_grad():
+        out = O.forward(P, cfg, g5["in.input_ids"], g5["in.attention_mask"])
+    assert maxabs(out["logits"], gb["logits"]) < 5e-5
+
+
+def test_g7_misc_bit_exact(golden):
+    g = golden("G7_misc")
+    assert torch.equal(MO.get_mask(g["video_len"], 10), g["get_mask"])
+    assert MO.get_mask(g["video_len"], 10).dtype == torch.int64
+    for seed in (0, 1):
+        ids = g[f"ids_{seed}"].clone()
+        special = (ids == 1) | (ids == 2)
+        torch.manual_seed(seed)
+        inp, lab = MO.mask_tokens(ids, special, 0, 4, 1000, 0.15)
+        assert torch.equal(inp, g[f"inputs_{seed}"])
+        assert torch.equal(lab, g[f"labels_{seed}"])
+    lrs = []
+    for sched in ("", "linear_with_warmup"):
+        for step in (0, 1, 9, 10, 11, 50, 99, 100):
+            lrs.append(MO.lr_at(step, 100, 3e-4, sched, 0.1))
+    assert np.array_equal(np.array(lrs), g["lrs"].numpy())
+
+
+def test_g9_answer_head(golden):
+    g = golden("G9_answers")
+    cfg = _tiny_cfg(n_ans=50)
+    P = O.synth_params(cfg, seed=9, std=0.05, ln_jitter=0.1)
+    emb = O.answer_embeddings(g["a2tok"], P, cfg)
+    assert maxabs(emb, g["answer_embeddings"]) < 1e-6
+    P["answer_embeddings.weight"] = emb
+    # reference assigns `answer_bias.weight = ...` (an attribute), the effective bias stays as initialised
+    P["answer_bias"] = g["answer_bias"]
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    with torch.no_grad():
+        out = O.forward(P, cfg, **batch)
+    assert maxabs(out["logits"], g["logits"]) < 5e-5
+    top10 = out["logits"].softmax(-1).topk(10, -1).indices
+    assert torch.equal(top10, g["top10"])
