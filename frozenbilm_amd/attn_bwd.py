@@ -1,0 +1,59 @@
+"""Host-side orchestration of the disentangled-attention backward (see csrc/attn_bwd.hip for the math).
+
+    dO --rowdot--> D            K,Q,dO --head_transpose--> K^T, Q^T, dO^T (head-major [nh,64,B,Sp])
+    kernel A : dV, dS, dS^T
+    shear(0) : dQ = dS.K   + G1.PK   (+ G1^T)        shear(1) : dK = dS^T.Q + G2.PQ   (+ G2^T)
+    GEMM     : dPK[h] = G1^T[h] . Q^T[h]^T           GEMM     : dPQ[h] = G2^T[h] . K^T[h]^T     (split-K, per head)
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import lib as L
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
+    B, S, H, nh, span2 = run.B, run.S, eng.H, eng.nh, eng.span2
+    Sp = (S + 63) // 64 * 64
+    dev = eng.dev
+    qkv = sv.qkv
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    pq, pk = sv.pqk[:, :H], sv.pqk[:, H:]
+    relidx = eng.relidx(S)
+    scale = 1.0 / math.sqrt(64 * 3)
+
+    Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
+    L.attn_rowdot(dctx, sv.ctx, Dv, B, S, nh)
+    dOT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+    KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+    QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+    L.head_transpose(dctx, dOT, B, S, Sp, nh, head_major=True)
+    L.head_transpose(k, KT, B, S, Sp, nh, head_major=True)
+    L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
+    dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
+    dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
+    L.disent_attn_bwd_ds(q, k, v, dctx, dOT, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
+                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, t_head_major=True)
+    del dOT
+    PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
+    PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
+    L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
+    L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
+    G1T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
+    G2T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
+    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2)
+    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2)
+    del dS, dST
+    # position tables: fp32 [span2, 2H] laid out [dPQ | dPK]; head h writes columns h*64 .. h*64+63
+    dpos = torch.zeros(span2, 2 * H, dtype=F32, device=dev)
+    Kc = B * Sp
+    sk = max(2, min(16, Kc // 1024))
+    o_pk = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), H)
+    o_pq = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), 0)
+    L.gemm(G1T, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk)
+    L.gemm(G2T, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk)
+    L.cast_bf16(dpos, dpqk)

@@ -1,0 +1,255 @@
+// Fused disentangled self-attention forward for gfx950 (DeBERTa-v2: c2p + p2c relative-position bias, share_att_key).
+//
+//   score[i,j] = scale * ( Q_i.K_j + Q_i.PK[idx(i-j)] + K_j.PQ[idx(i-j)] ),   ctx = dropout(softmax_masked(score)) . V
+//   reference: model/deberta.py:717-818 + :820-947 + XSoftmax :100-138   
+//
+// One workgroup (4 waves) = one (batch, head, 64-query tile); it sweeps the keys in tiles of 64 with an online
+// softmax.  For a (query tile, key tile) pair the relative index idx(i-j) only spans <=127 consecutive rows of the
+// position tables (idx is monotone with slope <= 1 in delta), so both bias terms are MFMA GEMMs against a 128-row
+// WINDOW of PK / PQ staged in LDS:   T1 = Q_tile . PKwin^T  [64 x 128],   T2 = K_tile . PQwin^T  [64 x 128]
+// followed by an LDS gather  c2p[i,j] = T1[i][idx(i-j)-lo],  p2c[i,j] = T2[j][idx(i-j)-lo].  Nothing of size SxS or
+// Sx512 ever reaches HBM.  All MFMAs are "swapped" (keys/positions as A rows, queries as B columns): a lane owns ONE
+// query column, so softmax statistics are in-lane + 2 shuffles, and P feeds the P.V MFMA straight from registers
+// (the k-slot order of that MFMA is permuted identically on the V^T operand).
+#include "fbl_common.h"
+#include "../../include/fbl.h"
+
+namespace {
+
+constexpr int LDT = 132;  // fp32 row stride of T1/T2 (528 B: 16B-aligned rows, spreads banks)
+constexpr int LDV = 72;   // bf16 row stride of the V^T tile (144 B: conflict-free ds_read_b64)
+
+struct AttnArgs {
+  const bf16* q; const bf16* k; const bf16* vt; const bf16* pk; const bf16* pq;
+  long ldq, ldk, ldp;
+  long v_sh, v_sb, v_sd;
+  const int16_t* relidx;
+  const int32_t* mask;
+  float scale, p_drop;
+  uint64_t seed;
+  bf16* ctx;
+  long ldo;
+  float* lse;
+  int B, S, Sp, nh, span2;
+};
+
+constexpr int SM_KS = 0;                         // [64][64] bf16, 16B chunks XOR-swizzled by row&7
+constexpr int SM_VT = SM_KS + 64 * 128;          // [64 d][72] bf16
+constexpr int SM_PK = SM_VT + 64 * LDV * 2;      // [128][64] bf16 swizzled
+constexpr int SM_PQ = SM_PK + 128 * 128;         // [128][64] bf16 swizzled
+constexpr int SM_T1 = SM_PQ + 128 * 128;         // [4 waves][16][LDT] fp32
+constexpr int SM_T2 = SM_T1 + 4 * 16 * LDT * 4;  // [64][LDT] fp32
+constexpr int SM_IDX = SM_T2 + 64 * LDT * 4;     // int16 [1024]
+constexpr int SM_KM = SM_IDX + 2048;             // float [64] key validity
+constexpr int SM_TOTAL = SM_KM + 256;
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int chunk) {
+  // swizzled [rows][8 chunks of 16B] image
+  return *(const bf16x8*)(base + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int S = a.S;
+  const int i = i0 + w * 16 + c;  // this lane's query row
+  const int ic = min(i, S - 1);
+
+  int16_t* idx = (int16_t*)(smem + SM_IDX);
+  float* kms = (float*)(smem + SM_KM);
+  float* T1w = (float*)(smem + SM_T1) + w * 16 * LDT;
+  float* T2 = (float*)(smem + SM_T2);
+
+  for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
+
+  // Q fragments (B operand: column = query c, k-slots g*8..g*8+7 of each 32-wide d step)
+  bf16x8 qf[2];
+  {
+    const bf16* qp = a.q + ((long)b * S + ic) * a.ldq + h * 64 + g * 8;
+    qf[0] = *(const bf16x8*)qp;
+    qf[1] = *(const bf16x8*)(qp + 32);
+  }
+  const float qvalid = (i < S && a.mask[(long)b * S + ic] != 0) ? 1.f : 0.f;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t thr = fbl_drop_thresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const int nkt = (S + 63) / 64;
+  __syncthreads();  // idx table visible
+
+  for (int jt = 0; jt < nkt; ++jt) {
+    const int j0 = jt * 64;
+    const int dmin = min(max(i0 - (j0 + 63) + S - 1, 0), 2 * S - 2);
+    const int r_lo = idx[dmin];
+    // ---- stage K tile, V^T tile, PK/PQ windows, key mask
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int id = tid + t * 256;
+      const int row = id >> 3, ch = id & 7;
+      const int j = min(j0 + row, S - 1);
+      const bf16x8 kv = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + ch * 8);
+      *(bf16x8*)(smem + SM_KS + row * 128 + ((ch ^ (row & 7)) << 4)) = kv;
+      const bf16x8 vv = *(const bf16x8*)(a.vt + h * a.v_sh + b * a.v_sb + row * a.v_sd + j0 + ch * 8);
+      *(bf16x8*)(smem + SM_VT + row * (LDV * 2) + ch * 16) = vv;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int id = tid + t * 256;
+      const int row = id >> 3, ch = id & 7;
+      const int r = min(r_lo + row, a.span2 - 1);
+      const long off = (long)r * a.ldp + h * 64 + ch * 8;
+      *(bf16x8*)(smem + SM_PK + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const bf16x8*)(a.pk + off);
+      *(bf16x8*)(smem + SM_PQ + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const bf16x8*)(a.pq + off);
+    }
+    if (tid < 64) {
+      const int j = j0 + tid;
+      kms[tid] = (j < S && a.mask[(long)b * S + min(j, S - 1)] != 0) ? 1.f : 0.f;
+    }
+    __syncthreads();
+
+    // ---- (1) content scores, transposed: sacc[nt][r] = Q_i . K_j,  j = j0 + nt*16 + g*4 + r
+    f32x4 sacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const bf16x8 k0 = lds_frag(smem + SM_KS, nt * 16 + c, g);
+      const bf16x8 k1 = lds_frag(smem + SM_KS, nt * 16 + c, 4 + g);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], acc, 0, 0, 0);
+      sacc[nt] = acc;
+    }
+    // ---- (2) T1[query c][win] (wave private) and (3) T2[key w*16+c][win] (shared)
+    {
+      const bf16x8 kb0 = lds_frag(smem + SM_KS, w * 16 + c, g);
+      const bf16x8 kb1 = lds_frag(smem + SM_KS, w * 16 + c, 4 + g);
+#pragma unroll
+      for (int wt = 0; wt < 8; ++wt) {
+        const bf16x8 p0 = lds_frag(smem + SM_PK, wt * 16 + c, g);
+        const bf16x8 p1 = lds_frag(smem + SM_PK, wt * 16 + c, 4 + g);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, qf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, qf[1], acc, 0, 0, 0);
+        *(f32x4*)(T1w + c * LDT + wt * 16 + g * 4) = acc;
+        const bf16x8 r0 = lds_frag(smem + SM_PQ, wt * 16 + c, g);
+        const bf16x8 r1 = lds_frag(smem + SM_PQ, wt * 16 + c, 4 + g);
+        f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r0, kb0, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, kb1, acc2, 0, 0, 0);
+        *(f32x4*)(T2 + (w * 16 + c) * LDT + wt * 16 + g * 4) = acc2;
+      }
+    }
+    __syncthreads();
+
+    // ---- (4) gather the bias terms, mask, online softmax
+    float p[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jl = nt * 16 + g * 4 + r;
+        const int di = min(max(i - (j0 + jl) + S - 1, 0), 2 * S - 2);
+        const int wi = min(max((int)idx[di] - r_lo, 0), 127);
+        float s = (sacc[nt][r] + T1w[c * LDT + wi] + T2[jl * LDT + wi]) * a.scale;
+        s = (kms[jl] * qvalid != 0.f) ? s : -INFINITY;
+        p[nt * 4 + r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float alpha = 1.f, psum = 0.f;
+    if (m_new == -INFINITY) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) p[e] = 0.f;
+    } else {
+      alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        p[e] = __expf(p[e] - m_new);
+        psum += p[e];
+      }
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    if (a.p_drop > 0.f) {
+      const uint64_t rowbase = (((uint64_t)b * a.nh + h) * S + (uint64_t)ic) * S;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p[nt * 4 + r] *= fbl_dropout_scale(a.seed, rowbase + (uint64_t)(j0 + nt * 16 + g * 4 + r), thr, inv_keep);
+    }
+    // ---- (5) O^T += V^T . P^T ; k-slot e of step kk  <->  key kk*32 + (e>>2)*16 + g*4 + (e&3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = f2bf(p[(2 * kk) * 4 + e]);
+        pf[4 + e] = f2bf(p[(2 * kk + 1) * 4 + e]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char* vrow = smem + SM_VT + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 4) * 2;
+        const bf16x4 v0 = *(const bf16x4*)vrow;
+        const bf16x4 v1 = *(const bf16x4*)(vrow + 32);
+        bf16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[e] = v0[e];
+          vf[4 + e] = v1[e];
+        }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // LDS tiles are overwritten by the next key tile
+  }
+
+  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  if (i < S) {
+    bf16* op = a.ctx + ((long)b * S + i) * a.ldo + h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = o[dt] * inv_l;
+      *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    }
+    if (g == 0 && a.lse) a.lse[((long)b * a.nh + h) * S + i] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+  }
+}
+
+}  // namespace
+
+extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
+                                   int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp,
+                                   const int16_t* relidx,
+                                   const int32_t* mask, float scale, float p_drop, uint64_t seed, void* ctx,
+                                   int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if ((ldq % 8) || (ldk % 8) || (ldp % 8) || (ldo % 4) || (v_sh % 8) || (v_sb % 8) || (v_sd % 8)) return FBL_ERR_ALIGN;
+  if (B <= 0 || nh <= 0) return 0;
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, v_sh, v_sb, v_sd, relidx,
+             mask, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((S + 63) / 64, nh, B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), SM_TOTAL, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,61 @@
+// Device-side helpers shared by the gfx950 kernels of libfbl.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define FBL_WAVE 64
+
+#define FBL_CHECK_LAUNCH()                                     \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return (int)e__;                    \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE (v_cvt_pk_bf16_f32 on gfx950)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// Counter-based dropout RNG: keep decision is a pure function of (seed, element index), so backward
+// regenerates the mask instead of storing it.  Two rounds of a 64->32 bit multiply-xorshift mixer.
+__device__ __forceinline__ uint32_t fbl_hash(uint64_t seed, uint64_t idx) {
+  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+// returns the multiplicative factor: 0 (dropped) or 1/(1-p) (kept); p == 0 -> 1
+__device__ __forceinline__ float fbl_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return (fbl_hash(seed, idx) >= thresh) ? inv_keep : 0.0f;
+}
+// host+device: p -> 32-bit threshold (drop iff hash < thresh)
+static inline __host__ __device__ uint32_t fbl_drop_thresh(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}

@@ -1,0 +1,261 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( alpha * A[M,K] . B[N,K]^T )   ("NT": both operands K-contiguous)
+//
+// This one kernel serves every dense contraction of the FrozenBiLM hot path (reference: the nn.Linear calls of
+// model/deberta.py:255,311,329,757-765,847-853,1545 and model/adapter.py:38,42; their backward dX = dY.W is the
+// same kernel on the pre-transposed frozen weight).
+//
+// Structure (CDNA4): 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16
+// accumulators.  Operand tiles go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double-buffered,
+// one barrier per K-step.  LDS image is [128 rows][8 x 16B chunks] with chunk ^= row&7 applied on the SOURCE
+// address (LDS-DMA destinations are lane-linear) and again on the ds_read_b128 side -> conflict-free fragment reads.
+// MFMA operands are swapped (weights as "A", activations as "B") so each lane owns 4 consecutive output columns
+// -> 16-byte fp32 / 8-byte bf16 epilogue stores.
+#include "fbl_common.h"
+#include "../../include/fbl.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
+constexpr int NXCD = 8;
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  long lda, ldb;
+  int M, N, K;
+  const float* bias;      // [N] or null
+  const float* rowscale;  // [M] or null: multiplies (alpha*acc + bias) per row before the activation
+  float alpha;
+  int act, aux_kind;
+  const void* aux;
+  long ld_aux;
+  float* out_f32;
+  bf16* out_bf16;
+  bf16* out_pre;  // pre-activation copy (bf16) or null
+  long ldc;
+  long sA, sB, sC, sAux, sBias;  // batch strides in elements
+  int splitk;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int ACT, int AUX, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A tile | B tile)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile mapping: XCD-aware (block b runs on XCD b%8) + grouped along M so neighbours share the B panel in L2
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int pid = blockIdx.x;
+  {
+    const int q = ntiles / NXCD, r = ntiles % NXCD;
+    const int xcd = pid % NXCD, idx = pid / NXCD;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective remap
+  }
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * g.tiles_n;
+  const int group = pid / width;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(g.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % width) % gsz;
+  const int tn = (pid % width) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int batch = blockIdx.y / g.splitk;
+  const int ks = blockIdx.y % g.splitk;
+  const int nk_total = g.K / BK;
+  const int per = (nk_total + g.splitk - 1) / g.splitk;
+  const int kt0 = ks * per;
+  const int kt1 = min(nk_total, kt0 + per);
+  if (kt0 >= kt1) return;
+
+  const bf16* A = g.A + (long)batch * g.sA;
+  const bf16* B = g.B + (long)batch * g.sB;
+
+  // ---- LDS-DMA source addressing: instruction q covers rows (q*4+wave)*8 .. +8; lane -> row lane>>3, phys chunk lane&7
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;  // logical 16B chunk fetched by this lane (row&7 == lrow)
+  const bf16* a_src[4];
+  const bf16* b_src[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (q * 4 + wave) * 8 + lrow;
+    const int am = min(m0 + row, g.M - 1);
+    const int bn = min(n0 + row, g.N - 1);
+    a_src[q] = A + (long)am * g.lda + lchunk * 8;
+    b_src[q] = B + (long)bn * g.ldb + lchunk * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+    char* base = smem + stage * STAGE_BYTES;
+    const long koff = (long)kt * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int off = (q * 4 + wave) * 1024;
+      glds16(a_src[q] + koff, base + off);
+      glds16(b_src[q] + koff, base + TILE_BYTES + off);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a tile: row*128 + ((s*4 + lane>>4) ^ (row&7))*16
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = (wm * 64 + i * 16 + frow) * 128;
+    b_off[i] = TILE_BYTES + (wn * 64 + i * 16 + frow) * 128;
+  }
+
+  issue(kt0, 0);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int stage = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+    const char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int pc = ((s * 4 + fg) ^ fsw) * 16;
+      bf16x8 af[4], bfg[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const bf16x8*)(base + a_off[i] + pc);
+        bfg[i] = *(const bf16x8*)(base + b_off[i] + pc);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns C[m][n4..n4+3],  m = m0+wm*64+mi*16+(lane&15),  n4 = n0+wn*64+ni*16+(lane>>4)*4
+  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+  const long cbase = (long)batch * g.sC;
+  const long xbase = (long)batch * g.sAux;
+  const bool vec_ok = ((g.ldc & 3) == 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + frow;
+    if (m >= g.M) continue;
+    const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n4 = n0 + wn * 64 + ni * 16 + fg * 4;
+      if (n4 >= g.N) continue;
+      float v[4], pre[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * g.alpha;
+      const bool full = (n4 + 3 < g.N);
+      if (SPLITK) {
+        if (ks == 0 && bias)
+          for (int r = 0; r < 4; ++r)
+            if (n4 + r < g.N) v[r] += bias[n4 + r];
+        for (int r = 0; r < 4; ++r)
+          if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r] * rs);
+        continue;
+      }
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (n4 + r < g.N) ? bias[n4 + r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] *= rs;
+        pre[r] = v[r];
+        if (ACT == FBL_ACT_GELU) v[r] = gelu_erf(v[r]);
+        else if (ACT == FBL_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (AUX != FBL_AUX_NONE) {
+        const long ao = xbase + (long)m * g.ld_aux + n4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n4 + r >= g.N) break;
+          if (AUX == FBL_AUX_ADD_F32) v[r] += ((const float*)g.aux)[ao + r];
+          else if (AUX == FBL_AUX_ADD_BF16) v[r] += bf2f(((const bf16*)g.aux)[ao + r]);
+          else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(bf2f(((const bf16*)g.aux)[ao + r]));
+          else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (bf2f(((const bf16*)g.aux)[ao + r]) > 0.f) ? v[r] : 0.f;
+        }
+      }
+      const long co = cbase + (long)m * g.ldc + n4;
+      if (full && vec_ok) {
+        if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
+        if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if (g.out_pre) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};
+      } else {
+        for (int r = 0; r < 4; ++r) {
+          if (n4 + r >= g.N) break;
+          if (g.out_f32) g.out_f32[co + r] = v[r];
+          if (g.out_bf16) g.out_bf16[co + r] = f2bf(v[r]);
+          if (g.out_pre) g.out_pre[co + r] = f2bf(pre[r]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                                const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
+                                const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
+                                int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                                int64_t strideAux, int64_t strideBias, int splitk, void* stream) {
+  if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
+  if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && (!out_f32 || out_bf16 || out_pre_bf16 || act != FBL_ACT_NONE || aux_kind != FBL_AUX_NONE))
+    return FBL_ERR_ARG;  // split-K only accumulates (atomicAdd) into a pre-initialised fp32 output
+  if (!out_f32 && !out_bf16) return FBL_ERR_ARG;
+  GemmArgs g;
+  g.A = (const bf16*)A; g.B = (const bf16*)B; g.lda = lda; g.ldb = ldb;
+  g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.rowscale = rowscale; g.alpha = alpha; g.act = act; g.aux_kind = aux_kind;
+  g.aux = aux; g.ld_aux = ld_aux;
+  g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out_pre = (bf16*)out_pre_bf16; g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sAux = strideAux; g.sBias = strideBias;
+  g.splitk = splitk;
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + BN - 1) / BN;
+  dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
+  const int smem_bytes = 2 * STAGE_BYTES;
+#define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                                                                       \
+  do {                                                                                                         \
+    static bool attr_set = false;                                                                              \
+    auto kfn = gemm_bf16_nt_kernel<ACT_, AUX_, SK_>;                                                           \
+    if (!attr_set) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes); \
+      if (e != hipSuccess) return (int)e;                                                                      \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), smem_bytes, (hipStream_t)stream, g);                              \
+  } while (0)
+  if (splitk > 1) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
+  else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
+  else if (act == FBL_ACT_RELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_RELU, FBL_AUX_NONE, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADD_F32, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADD_BF16, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_POS_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_POS_BF16, false);
+  else return FBL_ERR_ARG;
+#undef FBL_GEMM_LAUNCH
+  FBL_CHECK_LAUNCH();
+  return 0;
+}

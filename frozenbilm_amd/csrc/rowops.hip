@@ -1,0 +1,708 @@
+// HBM-bound row / elementwise kernels of the FrozenBiLM hot path for gfx950 (wave64).
+// One wave owns one row (H <= 2048): the row lives in registers, statistics via wave shuffles, 16-byte accesses.
+#include "fbl_common.h"
+#include "../../include/fbl.h"
+
+namespace {
+
+template <int VEC>
+struct VecF {};
+template <>
+struct VecF<4> {
+  typedef f32x4 T;
+};
+template <>
+struct VecF<2> {
+  typedef f32x2 T;
+};
+
+template <int VEC>
+__device__ __forceinline__ void ldf(const float* p, float* v) {
+  if (VEC == 4) {
+    f32x4 x = *(const f32x4*)p;
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  } else if (VEC == 2) {
+    f32x2 x = *(const f32x2*)p;
+    v[0] = x[0]; v[1] = x[1];
+  } else {
+    v[0] = p[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stf(float* p, const float* v) {
+  if (VEC == 4) *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+  else if (VEC == 2) *(f32x2*)p = (f32x2){v[0], v[1]};
+  else p[0] = v[0];
+}
+template <int VEC>
+__device__ __forceinline__ void stb(bf16* p, const float* v) {
+  if (VEC == 4) *(bf16x4*)p = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  else if (VEC == 2) *(bf16x2*)p = (bf16x2){f2bf(v[0]), f2bf(v[1])};
+  else p[0] = f2bf(v[0]);
+}
+
+struct LnFwdArgs {
+  const float* y; long ldy; float p_drop; uint64_t seed;
+  const float* r_plain; const float* r_t; const float* r_stats; const float* r_gamma; const float* r_beta;
+  const int32_t* r_rowmask;
+  const float* gamma; const float* beta; float eps; const int32_t* rowmask;
+  float* out_t; float* out_stats; bf16* out_bf16; float* out_f32;
+  int N, H;
+};
+
+// EPL = elements per lane = H/64
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+  constexpr int VEC = (EPL % 4 == 0) ? 4 : ((EPL % 2 == 0) ? 2 : 1);
+  constexpr int NIT = EPL / VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.N) return;
+  const int H = a.H;
+  float v[EPL];
+  const uint32_t thr = fbl_drop_thresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  float rmean = 0.f, rrstd = 0.f, rmask = 1.f;
+  if (a.r_t) {
+    rmean = a.r_stats[2 * (long)row];
+    rrstd = a.r_stats[2 * (long)row + 1];
+    if (a.r_rowmask) rmask = (float)a.r_rowmask[row];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int col = (it * 64 + lane) * VEC;
+    float* vv = v + it * VEC;
+    if (a.y) {
+      ldf<VEC>(a.y + (long)row * a.ldy + col, vv);
+      if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) vv[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) vv[c] = 0.f;
+    }
+    if (a.r_plain) {
+      float r[VEC];
+      ldf<VEC>(a.r_plain + (long)row * H + col, r);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) vv[c] += r[c];
+    }
+    if (a.r_t) {
+      float r[VEC], gg[VEC], bb[VEC];
+      ldf<VEC>(a.r_t + (long)row * H + col, r);
+      ldf<VEC>(a.r_gamma + col, gg);
+      ldf<VEC>(a.r_beta + col, bb);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) vv[c] += ((r[c] - rmean) * rrstd * gg[c] + bb[c]) * rmask;
+    }
+    if (a.out_t) stf<VEC>(a.out_t + (long)row * H + col, vv);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) s += v[e];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const float d = v[e] - mean;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rstd = rsqrtf(var + a.eps);
+  if (lane == 0 && a.out_stats) {
+    a.out_stats[2 * (long)row] = mean;
+    a.out_stats[2 * (long)row + 1] = rstd;
+  }
+  const float om = a.rowmask ? (float)a.rowmask[row] : 1.0f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int col = (it * 64 + lane) * VEC;
+    float gg[VEC], bb[VEC], o[VEC];
+    ldf<VEC>(a.gamma + col, gg);
+    ldf<VEC>(a.beta + col, bb);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) o[c] = ((v[it * VEC + c] - mean) * rstd * gg[c] + bb[c]) * om;
+    if (a.out_bf16) stb<VEC>(a.out_bf16 + (long)row * H + col, o);
+    if (a.out_f32) stf<VEC>(a.out_f32 + (long)row * H + col, o);
+  }
+}
+
+struct LnMatArgs {
+  const float* t; const float* stats; const float* gamma; const float* beta; const int32_t* rowmask;
+  const float* add_bcast; int S; float* out_f32; bf16* out_bf16; int N, H;
+};
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_mat_kernel(LnMatArgs a) {
+  constexpr int VEC = (EPL % 4 == 0) ? 4 : ((EPL % 2 == 0) ? 2 : 1);
+  constexpr int NIT = EPL / VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.N) return;
+  const int H = a.H;
+  const float mean = a.stats[2 * (long)row], rstd = a.stats[2 * (long)row + 1];
+  const float om = a.rowmask ? (float)a.rowmask[row] : 1.0f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int col = (it * 64 + lane) * VEC;
+    float x[VEC], gg[VEC], bb[VEC], o[VEC];
+    ldf<VEC>(a.t + (long)row * H + col, x);
+    ldf<VEC>(a.gamma + col, gg);
+    ldf<VEC>(a.beta + col, bb);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) o[c] = ((x[c] - mean) * rstd * gg[c] + bb[c]) * om;
+    if (a.add_bcast) {
+      float p[VEC];
+      ldf<VEC>(a.add_bcast + (long)(row % a.S) * H + col, p);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) o[c] += p[c];
+    }
+    if (a.out_f32) stf<VEC>(a.out_f32 + (long)row * H + col, o);
+    if (a.out_bf16) stb<VEC>(a.out_bf16 + (long)row * H + col, o);
+  }
+}
+
+// ---- LayerNorm backward: persistent grid of LNB_BLOCKS blocks x 4 waves; each wave strides over rows and keeps its
+// dgamma/dbeta partial in registers; block-reduced through LDS into ws[block][2][H]; a second tiny kernel folds ws
+// into dgamma/dbeta (+=), deterministic.
+constexpr int LNB_BLOCKS = 256;
+struct LnBwdArgs {
+  const float* dout; const int32_t* rowmask; const float* t; const float* stats; const float* gamma;
+  float p_drop; uint64_t seed; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
+};
+template <int EPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+  constexpr int VEC = (EPL % 4 == 0) ? 4 : ((EPL % 2 == 0) ? 2 : 1);
+  constexpr int NIT = EPL / VEC;
+  __shared__ float red[4 * 2 * 64 * EPL];  // [wave][2][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H;
+  float dg[EPL], db[EPL], gam[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) dg[e] = db[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) ldf<VEC>(a.gamma + (it * 64 + lane) * VEC, gam + it * VEC);
+  const uint32_t thr = fbl_drop_thresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  for (int row = blockIdx.x * 4 + wave; row < a.N; row += gridDim.x * 4) {
+    const float mean = a.stats[2 * (long)row], rstd = a.stats[2 * (long)row + 1];
+    const float om = a.rowmask ? (float)a.rowmask[row] : 1.0f;
+    float g[EPL], xh[EPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int col = (it * 64 + lane) * VEC;
+      float d[VEC], x[VEC];
+      ldf<VEC>(a.dout + (long)row * H + col, d);
+      ldf<VEC>(a.t + (long)row * H + col, x);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const int e = it * VEC + c;
+        const float dd = d[c] * om;
+        xh[e] = (x[c] - mean) * rstd;
+        dg[e] += dd * xh[e];
+        db[e] += dd;
+        g[e] = dd * gam[e];
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int col = (it * 64 + lane) * VEC;
+      float dt[VEC], dy[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const int e = it * VEC + c;
+        dt[c] = rstd * (g[e] - s1 - xh[e] * s2);
+        dy[c] = dt[c];
+        if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+      }
+      if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
+      if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * H + col, dy);
+      if (a.out_dy_f32) stf<VEC>(a.out_dy_f32 + (long)row * H + col, dy);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int col = (it * 64 + lane) * VEC;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      red[(wave * 2 + 0) * H + col + c] = dg[it * VEC + c];
+      red[(wave * 2 + 1) * H + col + c] = db[it * VEC + c];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[w * 2 * H + i];
+    a.ws[(long)blockIdx.x * 2 * H + i] = s;
+  }
+}
+__global__ void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * H) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(long)b * 2 * H + i];
+  if (i < H) dgamma[i] += s;
+  else dbeta[i - H] += s;
+}
+
+__global__ void embed_gather_kernel(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
+                                    float* out) {
+  const int S = T + L;
+  const int row = blockIdx.x;  // b*S + s
+  const int b = row / S, s = row % S;
+  const float* src = (s < T) ? vproj + ((long)b * T + s) * H : E + ids[(long)b * L + (s - T)] * (long)H;
+  float* dst = out + (long)row * H;
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) *(f32x4*)(dst + c) = *(const f32x4*)(src + c);
+}
+
+__global__ void im2col3_kernel(const bf16* x, bf16* out, int B, int S, int H) {
+  const int row = blockIdx.x;
+  const int s = row % S;
+  const int chunks = 3 * H / 8;
+  for (int i = threadIdx.x; i < chunks; i += blockDim.x) {
+    const int k = (i * 8) / H, c = (i * 8) % H;
+    const int ss = s + k - 1;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ss >= 0 && ss < S) v = *(const bf16x8*)(x + ((long)row + k - 1) * H + c);
+    *(bf16x8*)(out + (long)row * 3 * H + i * 8) = v;
+  }
+}
+__global__ void col2im3_kernel(const float* dcol, float* dx, int B, int S, int H, int accumulate) {
+  const int row = blockIdx.x;
+  const int s = row % S;
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    f32x4 acc = accumulate ? *(const f32x4*)(dx + (long)row * H + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ss = s - k + 1;  // output position whose tap k reads input position s
+      if (ss >= 0 && ss < S) acc += *(const f32x4*)(dcol + ((long)row - k + 1) * 3 * H + k * H + c);
+    }
+    *(f32x4*)(dx + (long)row * H + c) = acc;
+  }
+}
+
+__global__ void dropout_gelu_fwd_kernel(const float* c, float p, uint64_t seed, float* out, long n) {
+  const uint32_t thr = fbl_drop_thresh(p);
+  const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = c[i];
+    if (p > 0.f) v *= fbl_dropout_scale(seed, (uint64_t)i, thr, ik);
+    out[i] = gelu_erf(v);
+  }
+}
+__global__ void dropout_gelu_bwd_kernel(const float* dy, const float* c, float p, uint64_t seed, bf16* ob, float* of,
+                                        long n) {
+  const uint32_t thr = fbl_drop_thresh(p);
+  const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float sc = p > 0.f ? fbl_dropout_scale(seed, (uint64_t)i, thr, ik) : 1.f;
+    const float g = dy[i] * dgelu_erf(c[i] * sc) * sc;
+    if (ob) ob[i] = f2bf(g);
+    if (of) of[i] = g;
+  }
+}
+
+// 64x64 tile transpose through LDS; output rows are the input columns, zero-padded to rows_pad.
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void transpose_kernel(const void* in_, long ld_in, int rows, int cols, bf16* out,
+                                                        long rows_pad) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols)
+      v = IN_BF16 ? bf2f(((const bf16*)in_)[(long)r * ld_in + c]) : ((const float*)in_)[(long)r * ld_in + c];
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows_pad) out[(long)c * rows_pad + r] = f2bf(tile[tx][i]);
+  }
+}
+
+constexpr int CS_BLOCKS = 128;
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* in_, long ld_in, int rows, int cols, float* ws) {
+  // block handles a strided set of rows for a 256-wide column slab
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+      s += IN_BF16 ? bf2f(((const bf16*)in_)[(long)r * ld_in + c]) : ((const float*)in_)[(long)r * ld_in + c];
+  if (c < cols) ws[(long)blockIdx.x * cols + c] = s;
+}
+__global__ void colsum_fold_kernel(const float* ws, int nblk, int cols, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(long)b * cols + c];
+  out[c] += s;
+}
+
+// Vt[b,h,d,s] = V[b*S+s, h*64+d]; one block per (s-tile of 64, h, b)
+__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16* v, long ldv, bf16* vt, int B, int S, int Sp,
+                                                             int nh, long sh, long sb, long sd) {
+  __shared__ bf16 tile[64][66];
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int s = s0 + i;
+    tile[i][tx] = (s < S) ? v[((long)b * S + s) * ldv + h * 64 + tx] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int d = ty; d < 64; d += 4) {
+    const int s = s0 + tx;
+    if (s < Sp) vt[h * sh + b * sb + d * sd + s] = tile[tx][d];
+  }
+}
+
+// ---- cross entropy
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, long ldv, const int64_t* labels, int N, int V,
+                                                     float* row_lse, float* loss_sum_cnt) {
+  const int row = blockIdx.x;
+  const int64_t lab = labels[row];
+  if (lab < 0) {
+    if (threadIdx.x == 0) row_lse[row] = 0.f;
+    return;
+  }
+  __shared__ float red[4];
+  const float* x = logits + (long)row * ldv;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) s += __expf(x[i] - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float lse = m + logf(red[0] + red[1] + red[2] + red[3]);
+    row_lse[row] = lse;
+    atomicAdd(loss_sum_cnt, lse - x[lab]);
+    atomicAdd(loss_sum_cnt + 1, 1.0f);
+  }
+}
+__global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, long ldv, const int64_t* labels,
+                                                          const int32_t* rows, int V, int Vp, const float* row_lse,
+                                                          const float* loss_sum_cnt, float gscale, bf16* out) {
+  const int r = blockIdx.x;
+  const int row = rows[r];
+  const int64_t lab = labels[row];
+  const float lse = row_lse[row];
+  const float sc = gscale / fmaxf(loss_sum_cnt[1], 1.0f);
+  const float* x = logits + (long)row * ldv;
+  bf16* o = out + (long)r * Vp;
+  for (int i = threadIdx.x; i < Vp; i += 256) {
+    float g = 0.f;
+    if (i < V) g = (__expf(x[i] - lse) - (i == lab ? 1.f : 0.f)) * sc;
+    o[i] = f2bf(g);
+  }
+}
+
+__global__ void gather_rows_bf16_kernel(const bf16* in, long ld, const int32_t* rows, int cols, bf16* out) {
+  const int r = blockIdx.x;
+  const bf16* src = in + (long)rows[r] * ld;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) *(bf16x8*)(out + (long)r * cols + c) = *(const bf16x8*)(src + c);
+}
+__global__ void scatter_rows_f32_kernel(const float* in, const int32_t* rows, int cols, float* out, long ld) {
+  const int r = blockIdx.x;
+  float* dst = out + (long)rows[r] * ld;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[c] += in[(long)r * cols + c];
+}
+
+__global__ void sumsq_kernel(const float* x, long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                                 float eps, float wd, float bc1, float bc2, const float* sumsq, float max_norm,
+                                 float grad_scale) {
+  float clip = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(sumsq[0]) * grad_scale;
+    clip *= fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * clip;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void cast_bf16_kernel(const float* in, bf16* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+__global__ void dropout_f32_kernel(const float* in, float p, uint64_t seed, float* of, bf16* ob, long n) {
+  const uint32_t thr = fbl_drop_thresh(p);
+  const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = in[i];
+    if (p > 0.f) v *= fbl_dropout_scale(seed, (uint64_t)i, thr, ik);
+    if (of) of[i] = v;
+    if (ob) ob[i] = f2bf(v);
+  }
+}
+__global__ void dropout_bf16_kernel(bf16* x, float p, uint64_t seed, long n) {
+  const uint32_t thr = fbl_drop_thresh(p);
+  const float ik = 1.f / (1.f - p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    x[i] = f2bf(bf2f(x[i]) * fbl_dropout_scale(seed, (uint64_t)i, thr, ik));
+}
+
+inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
+  long b = (n + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define FBL_EPL_DISPATCH(H, KERNEL, GRID, ARGS, STREAM)                                              \
+  switch ((H) / 64) {                                                                                \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, STREAM, ARGS); break;                  \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, STREAM, ARGS); break;                  \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, STREAM, ARGS); break;                  \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, STREAM, ARGS); break;                  \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, GRID, dim3(256), 0, STREAM, ARGS); break;                \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, STREAM, ARGS); break;                \
+    case 24: hipLaunchKernelGGL(KERNEL<24>, GRID, dim3(256), 0, STREAM, ARGS); break;                \
+    case 32: hipLaunchKernelGGL(KERNEL<32>, GRID, dim3(256), 0, STREAM, ARGS); break;                \
+    default: return FBL_ERR_SHAPE;                                                                   \
+  }
+
+extern "C" int fbl_abi_version(void) { return 1; }
+
+extern "C" int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
+                                float* out_t, void* stream) {
+  if (H % 4) return FBL_ERR_SHAPE;
+  if (T > 0 && !vproj) return FBL_ERR_ARG;
+  if (B * (T + L) <= 0) return 0;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(B * (T + L)), dim3(128), 0, (hipStream_t)stream, ids, E, vproj, B, T, L,
+                     H, out_t);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const float* r_plain,
+                          const float* r_t, const float* r_stats, const float* r_gamma, const float* r_beta,
+                          const int32_t* r_rowmask, const float* gamma, const float* beta, float eps,
+                          const int32_t* rowmask, float* out_t, float* out_stats, void* out_bf16, float* out_f32, int N,
+                          int H, void* stream) {
+  if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
+  if (r_t && (!r_stats || !r_gamma || !r_beta)) return FBL_ERR_ARG;
+  if (N <= 0) return 0;
+  LnFwdArgs a{y, ldy, p_drop, seed, r_plain, r_t, r_stats, r_gamma, r_beta, r_rowmask, gamma, beta, eps, rowmask,
+              out_t, out_stats, (bf16*)out_bf16, out_f32, N, H};
+  dim3 grid((N + 3) / 4);
+  FBL_EPL_DISPATCH(H, ln_fwd_kernel, grid, a, (hipStream_t)stream);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_ln_materialize(const float* t, const float* stats, const float* gamma, const float* beta,
+                                  const int32_t* rowmask, const float* add_bcast, int S, float* out_f32, void* out_bf16,
+                                  int N, int H, void* stream) {
+  if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
+  if (N <= 0) return 0;
+  LnMatArgs a{t, stats, gamma, beta, rowmask, add_bcast, S > 0 ? S : 1, out_f32, (bf16*)out_bf16, N, H};
+  dim3 grid((N + 3) / 4);
+  FBL_EPL_DISPATCH(H, ln_mat_kernel, grid, a, (hipStream_t)stream);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t fbl_ln_bwd_ws_floats(int H) { return (int64_t)LNB_BLOCKS * 2 * H; }
+extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats,
+                          const float* gamma, float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16,
+                          float* out_dy_f32, float* dgamma, float* dbeta, float* ws, int N, int H, void* stream) {
+  if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
+  if (N <= 0) return 0;
+  LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H};
+  int nblk = (N + 3) / 4;
+  if (nblk > LNB_BLOCKS) nblk = LNB_BLOCKS;
+  dim3 grid(nblk);
+  FBL_EPL_DISPATCH(H, ln_bwd_kernel, grid, a, (hipStream_t)stream);
+  FBL_CHECK_LAUNCH();
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
+                       dgamma, dbeta);
+    FBL_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int fbl_im2col3(const void* x_bf16, void* out_bf16, int B, int S, int H, void* stream) {
+  if (H % 8) return FBL_ERR_SHAPE;
+  if (B * S <= 0) return 0;
+  hipLaunchKernelGGL(im2col3_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, (const bf16*)x_bf16,
+                     (bf16*)out_bf16, B, S, H);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_col2im3(const float* dcol, float* dx, int B, int S, int H, int accumulate, void* stream) {
+  if (H % 4) return FBL_ERR_SHAPE;
+  if (B * S <= 0) return 0;
+  hipLaunchKernelGGL(col2im3_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, S, H, accumulate);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, float* out_f32, int64_t n,
+                                    void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_gelu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, c, p_drop, seed,
+                     out_f32, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, void* out_bf16,
+                                    float* out_f32, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_gelu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, c, p_drop, seed,
+                     (bf16*)out_bf16, out_f32, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_transpose_to_bf16(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, void* out_bf16,
+                                     int64_t rows_pad, void* stream) {
+  if (rows_pad < rows) return FBL_ERR_ARG;
+  if (rows_pad <= 0 || cols <= 0) return 0;
+  dim3 grid((unsigned)((rows_pad + 63) / 64), (cols + 63) / 64);
+  if (in_is_bf16)
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols,
+                       (bf16*)out_bf16, (long)rows_pad);
+  else
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols,
+                       (bf16*)out_bf16, (long)rows_pad);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t fbl_colsum_ws_floats(int cols) { return (int64_t)CS_BLOCKS * cols; }
+extern "C" int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, float* out, float* ws,
+                          void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int nblk = rows < CS_BLOCKS ? rows : CS_BLOCKS;
+  dim3 grid(nblk, (cols + 255) / 256);
+  if (in_is_bf16)
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols, ws);
+  else
+    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols, ws);
+  FBL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nblk, cols,
+                     out);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, int S, int Sp, int nh,
+                                  int64_t out_sh, int64_t out_sb, int64_t out_sd, void* stream) {
+  if (Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if (B * S <= 0) return 0;
+  hipLaunchKernelGGL(head_transpose_kernel, dim3(Sp / 64, nh, B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)v_bf16, (long)ldv, (bf16*)vt_bf16, B, S, Sp, nh, (long)out_sh, (long)out_sb,
+                     (long)out_sd);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* labels, int N, int V, float* row_lse,
+                          float* loss_sum_cnt, void* stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, (long)ldv, labels, N, V,
+                     row_lse, loss_sum_cnt);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_ce_bwd_rows(const float* logits, int64_t ldv, const int64_t* labels, const int32_t* rows, int R,
+                               int V, int Vp, const float* row_lse, const float* loss_sum_cnt, float gscale,
+                               void* dlogits_bf16, void* stream) {
+  if (R <= 0) return 0;
+  if (Vp < V) return FBL_ERR_ARG;
+  hipLaunchKernelGGL(ce_bwd_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, (long)ldv, labels, rows, V,
+                     Vp, row_lse, loss_sum_cnt, gscale, (bf16*)dlogits_bf16);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_gather_rows_bf16(const void* in, int64_t ld, const int32_t* rows, int R, int cols, void* out,
+                                    void* stream) {
+  if (R <= 0) return 0;
+  if (cols % 8 || ld % 8) return FBL_ERR_ALIGN;
+  hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, (const bf16*)in, (long)ld,
+                     rows, cols, (bf16*)out);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_scatter_rows_f32(const float* in, const int32_t* rows, int R, int cols, float* out, int64_t ld,
+                                    void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, in, rows, cols, out,
+                     (long)ld);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n,
+                     out_sumsq);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, const float* sumsq, float max_norm,
+                             float grad_scale, void* stream) {
+  if (n <= 0) return 0;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2, sumsq, max_norm, grad_scale);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, float* out_f32, void* out_bf16,
+                               int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, p_drop, seed, out_f32,
+                     (bf16*)out_bf16, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, int64_t n, void* stream) {
+  if (n <= 0 || p_drop <= 0.f) return 0;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (bf16*)inout_bf16, p_drop,
+                     seed, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}

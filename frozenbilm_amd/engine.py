@@ -1,0 +1,735 @@
+"""Explicit forward / backward pipelines of the FrozenBiLM masked-LM hot path on MI355X.
+
+No tracing compiler and no ATen math: the step is a fixed sequence of C-ABI kernel launches (lib.py -> libfbl.so)
+on the current HIP stream; torch only owns HBM allocations.  Semantics follow SURVEY.md App. C / the reference lines
+quoted per stage.  Precision: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm statistics /
+softmax / logits / gradients of the trainable parameters.
+
+Residual stream representation: a LayerNorm output is kept as (t, stats, gamma, beta[, rowmask]) -- the pre-norm
+fp32 tensor plus per-row (mean, rstd) -- together with its bf16 copy (the next GEMM operand).  Consumers re-normalise
+on the fly, so the fp32 normalised tensor is never written to HBM, and ``t`` doubles as the tensor saved for backward.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .model.relpos import rel_index_vector
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class NormRef:
+    """A tensor given in LayerNorm-normalised form (see module docstring)."""
+    t: torch.Tensor
+    stats: torch.Tensor
+    gamma: torch.Tensor
+    beta: torch.Tensor
+    rowmask: Optional[torch.Tensor] = None
+
+    def as_args(self):
+        return (self.t, self.stats, self.gamma, self.beta, self.rowmask)
+
+
+@dataclass
+class Stream:
+    """One activation stream: bf16 GEMM operand + its fp32 value as NormRef or plain tensor."""
+    bf16: torch.Tensor
+    norm: Optional[NormRef] = None
+    plain: Optional[torch.Tensor] = None
+
+
+class Engine:
+    def __init__(self, model):
+        self.m = model
+        cfg = model.config
+        self.cfg = cfg
+        self.H, self.I, self.V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        self.nh = cfg.num_attention_heads
+        self.nL = cfg.num_hidden_layers
+        self.span2 = 2 * cfg.att_span
+        self.F = model.features_dim
+        self.Fp = _ru(self.F, 64) if self.F else 0
+        self.A1 = self.H // model.ds_factor_attn if model.ds_factor_attn else 0
+        self.A2 = self.H // model.ds_factor_ff if model.ds_factor_ff else 0
+        self.Vp = _ru(self.V, 64)
+        dev = model.device
+        if dev.type != "cuda":
+            raise RuntimeError("frozenbilm_amd runs on MI355X only: move the model to a cuda (HIP) device; "
+                               "there is no CPU fallback")
+        L.load()
+        self.dev = dev
+        self._build_flat()
+        self._pack_frozen()
+        self._relidx: Dict[int, torch.Tensor] = {}
+        self.reducer = None  # set by parallel.GradReducer for data-parallel training
+        self.skip_dead_layer = True
+        self._ln_ws = L.ln_bwd_ws(self.H, dev)
+        self._cs_ws = L.colsum_ws(max(self.H, self.I), dev)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _build_flat(self):
+        """Re-home every trainable parameter into one flat fp32 buffer (and its grad into a flat grad buffer)."""
+        from .model.deberta import flat_order
+
+        m = self.m
+        named = dict(m.named_parameters())
+        train_names = [n for n, p in named.items() if p.requires_grad]
+        order = flat_order(self.cfg, train_names)
+        offs, total = {}, 0
+        for n in order:
+            offs[n] = total
+            total += _ru(named[n].numel(), 8)  # keep every view 32-byte aligned
+        self.flat = torch.zeros(total, dtype=F32, device=self.dev)
+        self.flat_grad = torch.zeros(total, dtype=F32, device=self.dev)
+        self.flat_bf16 = torch.zeros(total, dtype=BF16, device=self.dev)
+        self.offsets, self.order = offs, order
+        self.G: Dict[str, torch.Tensor] = {}
+        self.Pb: Dict[str, torch.Tensor] = {}
+        for n in order:
+            p = named[n]
+            o, k = offs[n], p.numel()
+            view = self.flat[o:o + k].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            self.G[n] = self.flat_grad[o:o + k].view(p.shape)
+            self.Pb[n] = self.flat_bf16[o:o + k].view(p.shape)
+        self.P = {n: p.data for n, p in named.items()}
+        self.named = named
+        # bucket boundaries (one bucket per backward stage) for the gradient all-reduce
+        self.bucket_ends: Dict[str, int] = {}
+        for n in order:
+            key = self._bucket_key(n)
+            self.bucket_ends[key] = offs[n] + _ru(named[n].numel(), 8)
+
+    def _bucket_key(self, name: str) -> str:
+        if name.startswith("lm_predictions."):
+            return "head"
+        if name.startswith("deberta.encoder.layer."):
+            return "layer" + name.split(".")[3]
+        if name.startswith("deberta.encoder.conv."):
+            return "layer0" if False else "conv"
+        if name.startswith("deberta.encoder.LayerNorm"):
+            return "relln"
+        return "emb"
+
+    def attach_grads(self):
+        """Make p.grad the views of the flat grad buffer; zero it when the user dropped the grads (set_to_none)."""
+        fresh = all(self.named[n].grad is None for n in self.order)
+        if fresh:
+            self.flat_grad.zero_()
+        for n in self.order:
+            p = self.named[n]
+            if p.grad is None:
+                if not fresh:
+                    self.G[n].zero_()
+                p.grad = self.G[n]
+            elif p.grad.data_ptr() != self.G[n].data_ptr():
+                self.G[n].copy_(p.grad)
+                p.grad = self.G[n]
+
+    def _pack_frozen(self):
+        P, H, I = self.P, self.H, self.I
+        bf = lambda t: t.to(BF16).contiguous()
+        self.Lw = []
+        for i in range(self.nL):
+            p = f"deberta.encoder.layer.{i}"
+            s = p + ".attention.self."
+            Wqkv = torch.cat([P[s + "query_proj.weight"], P[s + "key_proj.weight"], P[s + "value_proj.weight"]], 0)
+            d = dict(
+                Wqkv=bf(Wqkv), WqkvT=bf(Wqkv.t()),
+                bqkv=torch.cat([P[s + "query_proj.bias"], P[s + "key_proj.bias"], P[s + "value_proj.bias"]]).float().contiguous(),
+                Wo=bf(P[p + ".attention.output.dense.weight"]), WoT=bf(P[p + ".attention.output.dense.weight"].t()),
+                bo=P[p + ".attention.output.dense.bias"].float().contiguous(),
+                Wi=bf(P[p + ".intermediate.dense.weight"]), WiT=bf(P[p + ".intermediate.dense.weight"].t()),
+                bi=P[p + ".intermediate.dense.bias"].float().contiguous(),
+                Wd=bf(P[p + ".output.dense.weight"]), WdT=bf(P[p + ".output.dense.weight"].t()),
+                bd=P[p + ".output.dense.bias"].float().contiguous(),
+            )
+            self.Lw.append(d)
+        if self.cfg.conv_kernel_size:
+            w = P["deberta.encoder.conv.conv.weight"]  # [H_out, H_in, 3] -> [H_out, k*H_in + c]
+            W2 = w.permute(0, 2, 1).reshape(H, 3 * H)
+            self.Wc, self.WcT = bf(W2), bf(W2.t())
+            self.bc = P["deberta.encoder.conv.conv.bias"].float().contiguous()
+        hd = "lm_predictions.lm_head."
+        self.Wh, self.WhT = bf(P[hd + "dense.weight"]), bf(P[hd + "dense.weight"].t())
+        self.bh = P[hd + "dense.bias"].float().contiguous()
+        E = P["deberta.embeddings.word_embeddings.weight"]
+        self.E32 = E.float().contiguous()
+        self.Eb = bf(E)
+        self.ETb = torch.zeros(H, self.Vp, dtype=BF16, device=self.dev)
+        self.ETb[:, : self.V] = E.t().to(BF16)
+        self.head_bias = P[hd + "bias"].float().contiguous()
+        self.rel_emb = P["deberta.encoder.rel_embeddings.weight"].float().contiguous()
+        self.pos_emb = P["deberta.embeddings.position_embeddings.weight"].float().contiguous()
+        if self.m.n_ans:
+            T = P["answer_embeddings.weight"]
+            self.n_ans = T.shape[0]
+            self.Ansb = bf(T)
+            self.ans_bias = P["answer_bias"].float().contiguous()
+
+    def relidx(self, S: int) -> torch.Tensor:
+        if S not in self._relidx:
+            v = rel_index_vector(S, self.cfg.position_buckets, self.cfg.max_rel, self.cfg.att_span)
+            self._relidx[S] = torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
+        return self._relidx[S]
+
+    def refresh_trainable_operands(self):
+        """bf16 MFMA operands of the trainable matrices (they change every optimizer step)."""
+        L.cast_bf16(self.flat, self.flat_bf16)
+        H = self.H
+        self.ad = []
+        for i in range(self.nL):
+            p = f"deberta.encoder.layer.{i}"
+            ent = {}
+            for key, blk, A in (("a1", ".attention.output.adapter", self.A1), ("a2", ".output.adapter", self.A2)):
+                if not A:
+                    continue
+                Ap = _ru(A, 64)
+                down = self.Pb[p + blk + ".down.weight"]  # [A,H]
+                up = self.Pb[p + blk + ".up.weight"]  # [H,A]
+                if Ap != A:
+                    upp = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
+                    upp[:, :A] = up
+                    up = upp
+                ent[key] = dict(down=down, up=up, A=A, Ap=Ap, name=p + blk,
+                                bd=self.P[p + blk + ".down.bias"], bu=self.P[p + blk + ".up.bias"])
+            self.ad.append(ent)
+        if self.F:
+            wv = self.Pb["deberta.embeddings.linear_video.weight"]
+            if self.Fp != self.F:
+                w2 = torch.zeros(H, self.Fp, dtype=BF16, device=self.dev)
+                w2[:, : self.F] = wv
+                wv = w2
+            self.Wv = wv
+
+    def _adapter_bwd_operands(self, ent):
+        """W^T operands for the adapter backward (trainable, so rebuilt per step, lazily per layer)."""
+        if "upT" not in ent:
+            A, Ap = ent["A"], ent["Ap"]
+            upT = self.Pb[ent["name"] + ".up.weight"].t().contiguous()  # [A,H]
+            downT = torch.zeros(self.H, Ap, dtype=BF16, device=self.dev)
+            downT[:, :A] = self.Pb[ent["name"] + ".down.weight"].t()
+            ent["upT"], ent["downT"] = upT, downT
+        return ent["upT"], ent["downT"]
+
+    # ------------------------------------------------------------------ public entry
+    def run(self, input_ids, attention_mask, video, video_mask, labels, mlm, want_hidden):
+        m = self.m
+        train = m.training
+        need_grad = torch.is_grad_enabled() and any(self.named[n].requires_grad for n in self.order)
+        if input_ids.device != self.dev:
+            raise RuntimeError(f"inputs must be on {self.dev}")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        B, Lt = input_ids.shape
+        use_video = bool(self.F) and video is not None
+        T = video.shape[1] if use_video else 0
+        S = T + Lt
+        if S > self.cfg.max_position_embeddings:
+            raise RuntimeError(
+                f"sequence of {S} positions (video {T} + text {Lt}) exceeds max_position_embeddings="
+                f"{self.cfg.max_position_embeddings} (the reference fails the same way, model/deberta.py:1020-1021,1392)")
+        if use_video:
+            if video_mask is None:
+                video_mask = torch.ones(video.shape[:2], device=self.dev, dtype=attention_mask.dtype)
+            mask = torch.cat([video_mask.to(attention_mask.dtype), attention_mask], 1)
+        else:
+            mask = attention_mask
+        mask = mask.to(torch.int32).contiguous()
+        full_labels = None
+        if labels is not None:
+            if use_video:
+                full_labels = torch.cat([torch.full((B, T), -100, dtype=torch.long, device=self.dev), labels], 1)
+            else:
+                full_labels = labels
+            full_labels = full_labels.contiguous().view(-1)
+        if train:
+            m.step_seed += 1
+        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=m.step_seed * 1000003 + 12345,
+                  p_hid=self.cfg.hidden_dropout_prob if train else 0.0,
+                  p_att=self.cfg.attention_probs_dropout_prob if train else 0.0,
+                  p_ad=m.adapter_dropout if train else 0.0)
+        run.mask = mask.view(-1)
+        run.labels = full_labels
+        self.refresh_trainable_operands()
+        use_ans = bool(m.n_ans) and not mlm
+        logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden)
+        Vout = self.n_ans if use_ans else self.V
+        res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None}
+        if want_hidden:
+            res["hidden_states"] = run.hidden_out
+        if full_labels is not None:
+            if need_grad:
+                res["loss"] = _StepFn.apply(self, run, loss_t, *[self.named[n] for n in self.order])
+            else:
+                res["loss"] = loss_t
+        return res
+
+    # ------------------------------------------------------------------ forward
+    def _ln(self, run, name, *, y, resid: Optional[Stream], N, p_drop=0.0, rowmask=None, want_f32=False):
+        H = self.H
+        g, b = self.P[name + ".weight"], self.P[name + ".bias"]
+        t = torch.empty(N, H, dtype=F32, device=self.dev)
+        stats = torch.empty(N, 2, dtype=F32, device=self.dev)
+        ob = torch.empty(N, H, dtype=BF16, device=self.dev)
+        of = torch.empty(N, H, dtype=F32, device=self.dev) if want_f32 else None
+        seed = run.next_seed() if p_drop > 0 else 0
+        r_norm = resid.norm.as_args() if resid is not None and resid.norm is not None else None
+        r_plain = resid.plain if resid is not None and r_norm is None else None
+        L.ln_fwd(y=y, p_drop=p_drop, seed=seed, r_plain=r_plain, r_norm=r_norm,
+                 gamma=g, beta=b, eps=self.cfg.layer_norm_eps, rowmask=rowmask, out_t=t, out_stats=stats, out_bf16=ob,
+                 out_f32=of, N=N, H=H)
+        return Stream(bf16=ob, norm=NormRef(t, stats, g, b, rowmask), plain=of), seed
+
+    def _adapter_fwd(self, run, ent, x_f32, x_bf16, N):
+        """y = x + up(drop(relu(down(x))))  (model/adapter.py:33-45) as two epilogue-fused GEMMs."""
+        A, Ap = ent["A"], ent["Ap"]
+        z = torch.zeros(N, Ap, dtype=BF16, device=self.dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=self.dev)
+        L.gemm(x_bf16, ent["down"], bias=ent["bd"], act=L.ACT_RELU, out_bf16=z, N=A)
+        seed = 0
+        if run.p_ad > 0:
+            seed = run.next_seed()
+            L.dropout_bf16_(z, run.p_ad, seed)
+        y = torch.empty(N, self.H, dtype=F32, device=self.dev)
+        L.gemm(z, ent["up"], bias=ent["bu"], aux=x_f32, aux_kind=L.AUX_ADD_F32, out_f32=y)
+        return y, z, seed
+
+    def _layer_fwd(self, run, li: int, kv: Stream, q: Optional[Stream], Rb: torch.Tensor):
+        """One execution of encoder layer ``li`` (model/deberta.py:351-375); q != None is the EMD form where the
+        query stream (and the attention residual, :290-292) differs from the key/value stream."""
+        W = self.Lw[li]
+        B, S, H, I, nh = run.B, run.S, self.H, self.I, self.nh
+        N = B * S
+        Sp = _ru(S, 64)
+        dev = self.dev
+        sv = LayerSave(li=li, emd=q is not None)
+        qkv = torch.empty(N, 3 * H, dtype=BF16, device=dev)
+        if q is None:
+            L.gemm(kv.bf16, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
+        else:
+            L.gemm(q.bf16, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
+            L.gemm(kv.bf16, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
+        # shared-key position projections (:847-853): [PQ | PK] = R . [Wq | Wk]^T
+        Rl = Rb
+        if run.p_hid > 0:  # pos_dropout (:779)
+            sv.seed_pos = run.next_seed()
+            Rl = torch.empty_like(Rb)
+            L.dropout_f32(run.R32, run.p_hid, sv.seed_pos, out_bf16=Rl)
+        pqk = torch.empty(self.span2, 2 * H, dtype=BF16, device=dev)
+        L.gemm(Rl, W["Wqkv"][: 2 * H], bias=W["bqkv"][: 2 * H], out_bf16=pqk)
+        vt = torch.empty(B, nh, 64, Sp, dtype=BF16, device=dev)
+        L.head_transpose(qkv[:, 2 * H:], vt, B, S, Sp, nh)
+        ctx = torch.empty(N, H, dtype=BF16, device=dev)
+        lse = torch.empty(B, nh, S, dtype=F32, device=dev)
+        sv.seed_att = run.next_seed() if run.p_att > 0 else 0
+        L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], self.relidx(S), run.mask_i32,
+                          1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
+                          seed=sv.seed_att)
+        # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
+        o32 = torch.empty(N, H, dtype=F32, device=dev)
+        ob = torch.empty(N, H, dtype=BF16, device=dev)
+        L.gemm(ctx, W["Wo"], bias=W["bo"], out_f32=o32, out_bf16=ob)
+        ad = self.ad[li]
+        y1, z1 = o32, None
+        if "a1" in ad:
+            y1, z1, sv.seed_ad1 = self._adapter_fwd(run, ad["a1"], o32, ob, N)
+        p = f"deberta.encoder.layer.{li}"
+        a, sv.seed_ln1 = self._ln(run, p + ".attention.output.LayerNorm", y=y1, resid=(q if q is not None else kv), N=N,
+                                  p_drop=run.p_hid)
+        # FFN: gelu(dense) -> dense -> adapter -> dropout -> LN(. + a)          (:310-313, :328-334)
+        h = torch.empty(N, I, dtype=BF16, device=dev)
+        hpre = torch.empty(N, I, dtype=BF16, device=dev) if run.save else None
+        L.gemm(a.bf16, W["Wi"], bias=W["bi"], act=L.ACT_GELU, out_bf16=h, out_pre=hpre)
+        f32 = torch.empty(N, H, dtype=F32, device=dev)
+        fb = torch.empty(N, H, dtype=BF16, device=dev)
+        L.gemm(h, W["Wd"], bias=W["bd"], out_f32=f32, out_bf16=fb)
+        y2, z2 = f32, None
+        if "a2" in ad:
+            y2, z2, sv.seed_ad2 = self._adapter_fwd(run, ad["a2"], f32, fb, N)
+        out, sv.seed_ln2 = self._ln(run, p + ".output.LayerNorm", y=y2, resid=Stream(bf16=a.bf16, norm=a.norm), N=N,
+                                    p_drop=run.p_hid)
+        if run.save:
+            sv.qkv, sv.vt, sv.pqk, sv.ctx, sv.lse = qkv, vt, pqk, ctx, lse
+            sv.ob, sv.z1, sv.ln1 = ob, z1, a.norm
+            sv.hpre, sv.fb, sv.z2, sv.ln2 = hpre, fb, z2, out.norm
+            run.layers.append(sv)
+        return out
+
+    def _forward(self, run, input_ids, video, use_ans, want_hidden):
+        cfg, H, dev = self.cfg, self.H, self.dev
+        B, S, T, Lt = run.B, run.S, run.T, run.Lt
+        N = B * S
+        run.mask_i32 = run.mask
+        mask_f = run.mask.to(F32)
+        run.mask_f = mask_f
+        # ---- embeddings (model/deberta.py:997-1058): cat(linear_video(video), E[ids]) -> LN -> *mask -> dropout
+        vproj = None
+        if T:
+            vb = torch.zeros(B * T, self.Fp, dtype=BF16, device=dev)
+            vb[:, : self.F] = video.reshape(B * T, self.F)
+            vproj = torch.empty(B * T, H, dtype=F32, device=dev)
+            L.gemm(vb, self.Wv, bias=self.P["deberta.embeddings.linear_video.bias"], out_f32=vproj)
+            run.video_bf16 = vb
+        t0 = torch.empty(N, H, dtype=F32, device=dev)
+        L.embed_gather(input_ids, self.E32, vproj, T, t0)
+        want_plain = run.p_hid > 0
+        emb, _ = self._ln(run, "deberta.embeddings.LayerNorm", y=t0, resid=None, N=N, rowmask=run.mask_i32,
+                          want_f32=want_plain)
+        run.emb_norm = emb.norm
+        if want_plain:  # post-LN dropout: materialise x0
+            run.seed_emb = run.next_seed()
+            L.dropout_f32(emb.plain, run.p_hid, run.seed_emb, out_f32=emb.plain, out_bf16=emb.bf16)
+            emb = Stream(bf16=emb.bf16, plain=emb.plain)
+        # ---- relative-position table: R = LayerNorm_enc(rel_embeddings.weight)   (:474-478)
+        r, _ = self._ln(run, "deberta.encoder.LayerNorm", y=self.rel_emb, resid=None, N=self.span2, want_f32=run.p_hid > 0)
+        run.rel_norm, run.R32, Rb = r.norm, r.plain, r.bf16
+        # ---- encoder (:507-575)
+        hs: List[Stream] = [emb]
+        x = emb
+        nL = self.nL
+        for i in range(nL):
+            if i == nL - 1 and self.skip_dead_layer and not want_hidden:
+                break  # its output feeds nothing; executed only when hidden_states are requested
+            if i == nL - 1:
+                keep, run.save = run.save, False
+                x = self._layer_fwd(run, i, x, None, Rb)
+                run.save = keep
+            else:
+                x = self._layer_fwd(run, i, x, None, Rb)
+            if i == 0 and cfg.conv_kernel_size:
+                x = self._conv_fwd(run, emb, x)
+            hs.append(x)
+        # ---- enhanced mask decoder (:1382-1412): q0 = pos_emb + hs[-2]; two passes of the last layer
+        kv = hs[nL - 1]
+        q32 = torch.empty(N, H, dtype=F32, device=dev)
+        qb = torch.empty(N, H, dtype=BF16, device=dev)
+        self._materialize(kv, add=self.pos_emb, S=S, out_f32=q32, out_bf16=qb)
+        q = Stream(bf16=qb, plain=q32)
+        for _ in range(2):
+            q = self._layer_fwd(run, nL - 1, kv, q, Rb)
+        if want_hidden:
+            run.hidden_out = tuple(self._materialize(s).view(B, S, H) for s in hs)
+        # ---- MLM head (:1544-1558): LN(gelu(dense(x))) . table^T + bias
+        hp = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(q.bf16, self.Wh, bias=self.bh, out_f32=hp)
+        hg = torch.empty(N, H, dtype=F32, device=dev)
+        L.dropout_gelu_fwd(hp, 0.0, 0, hg)
+        hl, _ = self._ln(run, "lm_predictions.lm_head.LayerNorm", y=hg, resid=None, N=N)
+        run.head_pre, run.head_norm, run.head_ln_bf16 = hp, hl.norm, hl.bf16
+        if use_ans:
+            Vout, table, bias = self.n_ans, self.Ansb, self.ans_bias
+        else:
+            Vout, table, bias = self.V, self.Eb, self.head_bias
+        ldv = _ru(Vout, 64)
+        logits = torch.empty(N, ldv, dtype=F32, device=dev)
+        L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
+        run.logits, run.Vout = logits, Vout
+        loss_t = None
+        if run.labels is not None:
+            run.row_lse = torch.empty(N, dtype=F32, device=dev)
+            run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
+            L.ce_fwd(logits, run.labels, Vout, run.row_lse, run.loss_acc)
+            loss_t = run.loss_acc[0] / run.loss_acc[1]  # mean over labelled rows (CrossEntropyLoss, :1483-1488)
+        return logits, loss_t
+
+    def _materialize(self, s: Stream, add=None, S=1, out_f32=None, out_bf16=None):
+        N, H = s.bf16.shape
+        if s.plain is not None and add is None and out_bf16 is None:
+            return s.plain
+        if out_f32 is None:
+            out_f32 = torch.empty(N, H, dtype=F32, device=self.dev)
+        if s.norm is not None:
+            n = s.norm
+            L.ln_materialize(n.t, n.stats, n.gamma, n.beta, rowmask=n.rowmask, add_bcast=add, S=S, out_f32=out_f32,
+                             out_bf16=out_bf16)
+        else:
+            v = s.plain if add is None else (s.plain.view(-1, S, H) + add[:S]).view(N, H)
+            out_f32.copy_(v)
+            if out_bf16 is not None:
+                out_bf16.copy_(v)
+        return out_f32
+
+    def _conv_fwd(self, run, emb: Stream, l0: Stream) -> Stream:
+        """ConvLayer (:395-419): LN(l0 + gelu(drop(mask * conv1d_k3(emb)))) * mask, conv as a K=3H GEMM on an im2col."""
+        B, S, H, dev = run.B, run.S, self.H, self.dev
+        N = B * S
+        col = torch.empty(N, 3 * H, dtype=BF16, device=dev)
+        L.im2col3(emb.bf16, col, B, S, H)
+        c = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(col, self.Wc, bias=self.bc, rowscale=run.mask_f, out_f32=c)
+        y = torch.empty(N, H, dtype=F32, device=dev)
+        run.seed_conv = run.next_seed() if run.p_hid > 0 else 0
+        L.dropout_gelu_fwd(c, run.p_hid, run.seed_conv, y)
+        out, _ = self._ln(run, "deberta.encoder.conv.LayerNorm", y=y, resid=l0, N=N, rowmask=run.mask_i32)
+        run.conv_c, run.conv_norm = c, out.norm
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True):
+        N, H = dout.shape
+        dt = torch.empty(N, H, dtype=F32, device=self.dev)
+        dyb = torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None
+        L.ln_bwd(dout, norm.t, norm.stats, norm.gamma, rowmask=norm.rowmask, p_drop=p_drop, seed=seed, out_dt=dt,
+                 out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], ws=self._ln_ws)
+        return dt, dyb
+
+    def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed):
+        """Backward of _adapter_fwd.  dyb: grad of the adapter output (bf16 [N,H]); returns grad of its input (bf16)."""
+        N, H = dyb.shape
+        A, Ap = ent["A"], ent["Ap"]
+        dev = self.dev
+        upT, downT = self._adapter_bwd_operands(ent)
+        dz = torch.zeros(N, Ap, dtype=BF16, device=dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=dev)
+        inv_keep = 1.0 / (1.0 - run.p_ad) if run.p_ad > 0 else 1.0
+        L.gemm(dyb, upT, alpha=inv_keep, aux=z, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=dz, N=A)
+        dx = torch.empty(N, H, dtype=BF16, device=dev)
+        L.gemm(dz, downT, aux=dyb, aux_kind=L.AUX_ADD_BF16, out_bf16=dx)
+        Np = _ru(N, 64)
+        dyT = torch.empty(H, Np, dtype=BF16, device=dev)
+        zT = torch.empty(Ap, Np, dtype=BF16, device=dev)
+        dzT = torch.empty(Ap, Np, dtype=BF16, device=dev)
+        xT = torch.empty(H, Np, dtype=BF16, device=dev)
+        L.transpose_to_bf16(dyb, dyT)
+        L.transpose_to_bf16(z, zT)
+        L.transpose_to_bf16(dz, dzT)
+        L.transpose_to_bf16(xin_b, xT)
+        sk = max(2, min(16, Np // 512))  # >= 2: the split-K path ACCUMULATES (atomicAdd) into the grad buffer
+        nm = ent["name"]
+        L.gemm(dyT, zT, out_f32=self.G[nm + ".up.weight"], N=A, splitk=sk)      # dWu[H,A] += dy^T z
+        L.gemm(dzT, xT, out_f32=self.G[nm + ".down.weight"], M=A, splitk=sk)    # dWd[A,H] += dz^T x
+        L.colsum(dyb, self.G[nm + ".up.bias"], self._cs_ws)
+        L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)
+        return dx
+
+    def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
+        """Backward of one layer execution.  dout: fp32 grad of its output.  Returns (dq_in, dkv_in) fp32 -- equal
+        streams are returned summed as (dx, None) for ordinary encoder layers."""
+        li = sv.li
+        W, ad = self.Lw[li], self.ad[li]
+        H, I, dev = self.H, self.I, self.dev
+        N = dout.shape[0]
+        p = f"deberta.encoder.layer.{li}"
+        dt2, dy2 = self._ln_bwd(p + ".output.LayerNorm", dout, sv.ln2, run.p_hid, sv.seed_ln2)
+        df = dy2
+        if "a2" in ad:
+            df = self._adapter_bwd(run, ad["a2"], dy2, sv.z2, sv.fb, sv.seed_ad2)
+        dh = torch.empty(N, I, dtype=BF16, device=dev)
+        L.gemm(df, W["WdT"], aux=sv.hpre, aux_kind=L.AUX_MUL_DGELU_BF16, out_bf16=dh)
+        da = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(dh, W["WiT"], aux=dt2, aux_kind=L.AUX_ADD_F32, out_f32=da)
+        del dh
+        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1)
+        do = dy1
+        if "a1" in ad:
+            do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
+        dctx = torch.empty(N, H, dtype=BF16, device=dev)
+        L.gemm(do, W["WoT"], out_bf16=dctx)
+        dqkv, dpqk = self._attn_bwd(run, sv, dctx)
+        # position tables: dR += [dPQ|dPK] . [Wq;Wk]   (through pos_dropout), accumulated over all layer executions
+        if run.p_hid > 0:
+            tmp = torch.empty(self.span2, H, dtype=F32, device=dev)
+            L.gemm(dpqk, W["WqkvT"][:, : 2 * H], out_f32=tmp)
+            L.dropout_f32(tmp, run.p_hid, sv.seed_pos, out_f32=tmp)
+            run.dR += tmp
+        else:
+            L.gemm(dpqk, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
+        if not sv.emd:
+            dx = torch.empty(N, H, dtype=F32, device=dev)
+            L.gemm(dqkv, W["WqkvT"], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dx)
+            return dx, None
+        dq = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dq)
+        dkv = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(dqkv[:, H:], W["WqkvT"][:, H:], out_f32=dkv)
+        return dq, dkv
+
+    def _attn_bwd(self, run, sv, dctx):
+        B, S, H, nh = run.B, run.S, self.H, self.nh
+        N = B * S
+        dqkv = torch.empty(N, 3 * H, dtype=BF16, device=self.dev)
+        dpqk = torch.empty(self.span2, 2 * H, dtype=BF16, device=self.dev)
+        from .attn_bwd import disent_attn_bwd
+
+        disent_attn_bwd(self, run, sv, dctx, dqkv, dpqk)
+        return dqkv, dpqk
+
+    def backward(self, run, gloss: torch.Tensor):
+        """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views)."""
+        if not run.save:
+            raise RuntimeError("forward was run without gradient bookkeeping")
+        cfg, H, dev = self.cfg, self.H, self.dev
+        B, S, T = run.B, run.S, run.T
+        N = B * S
+        self.attach_grads()
+        red = self.reducer
+        # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
+        rows = torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
+        R = rows.numel()
+        dq = torch.zeros(N, H, dtype=F32, device=dev)
+        if R > 0:
+            Vout = run.Vout
+            Vp = _ru(Vout, 64)
+            dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
+            L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+            if Vout == self.V:
+                tableT = self.ETb
+            else:
+                tableT = torch.zeros(H, Vp, dtype=BF16, device=dev)
+                tableT[:, :Vout] = self.Ansb.t()
+            dhl = torch.empty(R, H, dtype=F32, device=dev)
+            L.gemm(dlog, tableT, out_f32=dhl)
+            del dlog
+            rl = rows.long()
+            hn = run.head_norm
+            sub = NormRef(hn.t[rl].contiguous(), hn.stats[rl].contiguous(), hn.gamma, hn.beta)
+            dt, _ = self._ln_bwd("lm_predictions.lm_head.LayerNorm", dhl, sub, 0.0, 0, want_dy_bf16=False)
+            dpre = torch.empty(R, H, dtype=BF16, device=dev)
+            L.dropout_gelu_bwd(dt, run.head_pre[rl].contiguous(), 0.0, 0, out_bf16=dpre)
+            dqr = torch.empty(R, H, dtype=F32, device=dev)
+            L.gemm(dpre, self.WhT, out_f32=dqr)
+            L.scatter_rows_f32(dqr, rows, dq)
+        if red:
+            red.ready("head")
+        run.dR = torch.zeros(self.span2, H, dtype=F32, device=dev)
+        # ---- EMD: two executions of the last layer, newest first
+        layers = run.layers
+        d_kv_last = None
+        for _ in range(2):
+            sv = layers.pop()
+            dq, dkv = self._layer_bwd(run, sv, dq)
+            d_kv_last = dkv if d_kv_last is None else d_kv_last.add_(dkv)
+        dx = dq.add_(d_kv_last)  # q0 = pos_emb + hs[-2]: the query-stream grad flows into hs[-2] too
+        if red:
+            red.ready(f"layer{self.nL - 1}")
+        # ---- encoder layers nL-2 .. 0
+        while layers:
+            sv = layers.pop()
+            if sv.li == 0 and cfg.conv_kernel_size:
+                dx, dcol = self._conv_bwd(run, dx)
+                dx, _ = self._layer_bwd(run, sv, dx)
+                L.col2im3(dcol, dx, B, S, H, 1)
+                if red:
+                    red.ready("conv")
+            else:
+                dx, _ = self._layer_bwd(run, sv, dx)
+            if red:
+                red.ready(f"layer{sv.li}")
+        # ---- relative-position LayerNorm (receives grads from every layer execution)
+        rn = run.rel_norm
+        L.ln_bwd(run.dR, rn.t, rn.stats, rn.gamma, dgamma=self.G["deberta.encoder.LayerNorm.weight"],
+                 dbeta=self.G["deberta.encoder.LayerNorm.bias"], ws=self._ln_ws)
+        if red:
+            red.ready("relln")
+        # ---- embeddings: dropout -> *mask -> LN ; linear_video
+        if run.p_hid > 0:
+            L.dropout_f32(dx, run.p_hid, run.seed_emb, out_f32=dx)
+        en = run.emb_norm
+        dt0 = torch.empty(N, H, dtype=F32, device=dev)
+        L.ln_bwd(dx, en.t, en.stats, en.gamma, rowmask=en.rowmask, out_dt=dt0,
+                 dgamma=self.G["deberta.embeddings.LayerNorm.weight"], dbeta=self.G["deberta.embeddings.LayerNorm.bias"],
+                 ws=self._ln_ws)
+        if T:
+            dv = dt0.view(B, S, H)[:, :T].reshape(B * T, H).contiguous()
+            Kp = _ru(B * T, 64)
+            dvT = torch.empty(H, Kp, dtype=BF16, device=dev)
+            vT = torch.empty(self.Fp, Kp, dtype=BF16, device=dev)
+            L.transpose_to_bf16(dv, dvT)
+            L.transpose_to_bf16(run.video_bf16, vT)
+            L.gemm(dvT, vT, aux=self.G["deberta.embeddings.linear_video.weight"], aux_kind=L.AUX_ADD_F32,
+                   out_f32=self.G["deberta.embeddings.linear_video.weight"], N=self.F)
+            L.colsum(dv, self.G["deberta.embeddings.linear_video.bias"], self._cs_ws)
+        if red:
+            red.ready("emb")
+            red.finish()
+
+    def _conv_bwd(self, run, dout):
+        """Backward of _conv_fwd: returns (grad of the layer-0 output, grad of the im2col matrix)."""
+        B, S, H, dev = run.B, run.S, self.H, self.dev
+        N = B * S
+        cn = run.conv_norm
+        dt = torch.empty(N, H, dtype=F32, device=dev)
+        L.ln_bwd(dout, cn.t, cn.stats, cn.gamma, rowmask=cn.rowmask, out_dt=dt,
+                 dgamma=self.G["deberta.encoder.conv.LayerNorm.weight"],
+                 dbeta=self.G["deberta.encoder.conv.LayerNorm.bias"], ws=self._ln_ws)
+        dc = torch.empty(N, H, dtype=BF16, device=dev)
+        L.dropout_gelu_bwd(dt, run.conv_c, run.p_hid, run.seed_conv, out_bf16=dc)
+        dcol = torch.empty(N, 3 * H, dtype=F32, device=dev)
+        L.gemm(dc, self.WcT, rowscale=run.mask_f, out_f32=dcol)
+        return dt, dcol
+
+
+@dataclass
+class LayerSave:
+    li: int = 0
+    emd: bool = False
+    qkv: torch.Tensor = None
+    vt: torch.Tensor = None
+    pqk: torch.Tensor = None
+    ctx: torch.Tensor = None
+    lse: torch.Tensor = None
+    ob: torch.Tensor = None
+    z1: torch.Tensor = None
+    ln1: NormRef = None
+    hpre: torch.Tensor = None
+    fb: torch.Tensor = None
+    z2: torch.Tensor = None
+    ln2: NormRef = None
+    seed_pos: int = 0
+    seed_att: int = 0
+    seed_ad1: int = 0
+    seed_ad2: int = 0
+    seed_ln1: int = 0
+    seed_ln2: int = 0
+
+
+@dataclass
+class Run:
+    B: int
+    S: int
+    T: int
+    Lt: int
+    train: bool
+    save: bool
+    seed_base: int
+    p_hid: float
+    p_att: float
+    p_ad: float
+    layers: List[LayerSave] = field(default_factory=list)
+    _site: int = 0
+    mask: torch.Tensor = None
+    labels: torch.Tensor = None
+    hidden_out: tuple = None
+    seed_emb: int = 0
+    seed_conv: int = 0
+
+    def next_seed(self) -> int:
+        self._site += 1
+        return (self.seed_base * 0x9E3779B1 + self._site * 0x85EBCA77) & 0xFFFFFFFFFFFF
+
+
+class _StepFn(torch.autograd.Function):
+    """Single autograd node for the whole model: forward already ran; backward runs Engine.backward which writes the
+    gradients straight into the flat grad buffer (p.grad views), so autograd itself accumulates nothing."""
+
+    @staticmethod
+    def forward(ctx, engine, run, loss_t, *params):
+        ctx.engine, ctx.run = engine, run
+        return loss_t.detach().clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng, run = ctx.engine, ctx.run
+        eng.backward(run, gloss)
+        return (None, None, None) + tuple(None for _ in eng.order)

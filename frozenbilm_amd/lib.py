@@ -1,0 +1,358 @@
+"""ctypes binding of libfbl.so (include/fbl.h) + thin tensor-level wrappers.
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``) and the current HIP stream.  There is
+NO fallback: if the shared library is missing or a kernel returns an error, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfbl.so")
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16 = 0, 1, 2, 3, 4
+
+_vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); must mirror include/fbl.h (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "fbl_abi_version": (_i, []),
+    "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
+                              _l, _l, _l, _i, _vp]),
+    "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                        _vp]),
+    "fbl_ln_materialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "fbl_ln_bwd_ws_floats": (_l, [_i]),
+    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "fbl_im2col3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "fbl_col2im3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
+    "fbl_dropout_gelu_bwd": (_i, [_vp, _vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_transpose_to_bf16": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp]),
+    "fbl_colsum_ws_floats": (_l, [_i]),
+    "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
+    "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
+    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _f, _f, _u64, _vp, _l, _vp,
+                                 _i, _i, _i, _i, _i, _vp]),
+    "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
+    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f,
+                                    _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
+    "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
+    "fbl_scatter_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp]),
+    "fbl_sumsq": (_i, [_vp, _l, _vp, _vp]),
+    "fbl_adam_flat": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+    "fbl_cast_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
+    "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _l, _vp]),
+}
+
+_LIB = None
+
+
+def load(path: Optional[str] = None):
+    """Load libfbl.so and declare the ABI.  Raises if the library or any declared symbol is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: the FrozenBiLM MI355X path needs its HIP library (python -m frozenbilm_amd.build); "
+            "there is no CPU/eager fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(code: int, name: str):
+    if code != 0:
+        raise RuntimeError(f"{name} failed with code {code}")
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live in HBM (cuda device), got {t.device}")
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D row-major view (stride(1)==1), got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, aux_kind=AUX_NONE, out_f32=None,
+         out_bf16=None, out_pre=None, splitk=1, M=None, N=None):
+    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B: bf16 2-D views (or 3-D for strided batch)."""
+    _req(A, torch.bfloat16, "A")
+    _req(B, torch.bfloat16, "B")
+    batch = 1
+    sA = sB = sC = sX = 0
+    if A.dim() == 3:
+        batch = A.shape[0]
+        sA, sB = A.stride(0), (B.stride(0) if B.dim() == 3 else 0)
+        A2, B2 = A[0], (B[0] if B.dim() == 3 else B)
+    else:
+        A2, B2 = A, B
+    lda, ldb = _rows2d(A2, "A"), _rows2d(B2, "B")
+    Mv, K = A2.shape
+    Nv = B2.shape[0]
+    assert B2.shape[1] == K, (A2.shape, B2.shape)
+    M = Mv if M is None else M
+    N = Nv if N is None else N
+    ldc = None
+    for o, dt in ((out_f32, torch.float32), (out_bf16, torch.bfloat16), (out_pre, torch.bfloat16)):
+        if o is None:
+            continue
+        _req(o, dt, "out")
+        o2 = o[0] if o.dim() == 3 else o
+        l = _rows2d(o2, "out")
+        assert o2.shape[0] >= M and o2.shape[1] >= N, (o2.shape, M, N)
+        if ldc is None:
+            ldc = l
+            sC = o.stride(0) if o.dim() == 3 else 0
+        assert ldc == l, "all outputs of one GEMM must share the row stride"
+    ld_aux = 0
+    if aux is not None:
+        a2 = aux[0] if aux.dim() == 3 else aux
+        ld_aux = _rows2d(a2, "aux")
+        sX = aux.stride(0) if aux.dim() == 3 else 0
+        _req(aux, torch.float32 if aux_kind == AUX_ADD_F32 else torch.bfloat16, "aux")
+    sBias = 0
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+        if bias.dim() == 2:
+            sBias = bias.stride(0)
+    if rowscale is not None:
+        _req(rowscale, torch.float32, "rowscale")
+    code = load().fbl_gemm_bf16_nt(_p(A), lda, _p(B), ldb, M, N, K, _p(bias), _p(rowscale), float(alpha), act, aux_kind,
+                                   _p(aux), ld_aux, _p(out_f32), _p(out_bf16), _p(out_pre), ldc or 0, batch, sA, sB, sC,
+                                   sX, sBias, splitk, _stream())
+    _chk(code, "fbl_gemm_bf16_nt")
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+def embed_gather(ids, E, vproj, T, out_t):
+    B, L = ids.shape
+    H = E.shape[1]
+    _req(ids, torch.int64, "ids"); _req(E, torch.float32, "E"); _req(out_t, torch.float32, "out_t")
+    assert ids.is_contiguous() and E.is_contiguous() and out_t.is_contiguous()
+    if vproj is not None:
+        _req(vproj, torch.float32, "vproj")
+        assert vproj.is_contiguous()
+    _chk(load().fbl_embed_gather(_p(ids), _p(E), _p(vproj), B, T, L, H, _p(out_t), _stream()), "fbl_embed_gather")
+
+
+def ln_fwd(*, y=None, p_drop=0.0, seed=0, r_plain=None, r_norm=None, gamma, beta, eps, rowmask=None, out_t=None,
+           out_stats=None, out_bf16=None, out_f32=None, N, H):
+    """r_norm = (t, stats, gamma, beta, rowmask|None): residual given in LayerNorm-normalised form."""
+    ldy = 0
+    if y is not None:
+        _req(y, torch.float32, "y")
+        ldy = _rows2d(y, "y")
+    rt = rs = rg = rb = rm = None
+    if r_norm is not None:
+        rt, rs, rg, rb, rm = r_norm
+    for t in (r_plain, rt, out_t, out_bf16, out_f32):
+        if t is not None:
+            assert t.is_contiguous()
+    _chk(load().fbl_ln_fwd(_p(y), ldy, float(p_drop), int(seed), _p(r_plain), _p(rt), _p(rs), _p(rg), _p(rb), _p(rm),
+                           _p(gamma), _p(beta), float(eps), _p(rowmask), _p(out_t), _p(out_stats), _p(out_bf16),
+                           _p(out_f32), N, H, _stream()), "fbl_ln_fwd")
+
+
+def ln_materialize(t, stats, gamma, beta, rowmask=None, add_bcast=None, S=1, out_f32=None, out_bf16=None):
+    N, H = t.shape
+    _chk(load().fbl_ln_materialize(_p(t), _p(stats), _p(gamma), _p(beta), _p(rowmask), _p(add_bcast), S, _p(out_f32),
+                                   _p(out_bf16), N, H, _stream()), "fbl_ln_materialize")
+
+
+def ln_bwd_ws(H, device):
+    return torch.empty(load().fbl_ln_bwd_ws_floats(H), dtype=torch.float32, device=device)
+
+
+def ln_bwd(dout, t, stats, gamma, *, rowmask=None, p_drop=0.0, seed=0, out_dt=None, out_dy_bf16=None, out_dy_f32=None,
+           dgamma=None, dbeta=None, ws=None):
+    N, H = t.shape
+    assert dout.is_contiguous() and t.is_contiguous()
+    _chk(load().fbl_ln_bwd(_p(dout), _p(rowmask), _p(t), _p(stats), _p(gamma), float(p_drop), int(seed), _p(out_dt),
+                           _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(ws), N, H, _stream()),
+         "fbl_ln_bwd")
+
+
+def im2col3(x_bf16, out_bf16, B, S, H):
+    _chk(load().fbl_im2col3(_p(x_bf16), _p(out_bf16), B, S, H, _stream()), "fbl_im2col3")
+
+
+def col2im3(dcol, dx, B, S, H, accumulate):
+    _chk(load().fbl_col2im3(_p(dcol), _p(dx), B, S, H, int(accumulate), _stream()), "fbl_col2im3")
+
+
+def dropout_gelu_fwd(c, p_drop, seed, out_f32):
+    _chk(load().fbl_dropout_gelu_fwd(_p(c), float(p_drop), int(seed), _p(out_f32), c.numel(), _stream()),
+         "fbl_dropout_gelu_fwd")
+
+
+def dropout_gelu_bwd(dy, c, p_drop, seed, out_bf16=None, out_f32=None):
+    _chk(load().fbl_dropout_gelu_bwd(_p(dy), _p(c), float(p_drop), int(seed), _p(out_bf16), _p(out_f32), c.numel(),
+                                     _stream()), "fbl_dropout_gelu_bwd")
+
+
+def transpose_to_bf16(x, out, rows=None, cols=None):
+    """out[c, r] = x[r, c]; out is [cols, rows_pad] bf16 (zero padded)."""
+    ld = _rows2d(x, "x")
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    assert out.is_contiguous() and out.shape[0] >= cols
+    _req(out, torch.bfloat16, "out")
+    is_bf = 1 if x.dtype == torch.bfloat16 else 0
+    if not is_bf:
+        _req(x, torch.float32, "x")
+    _chk(load().fbl_transpose_to_bf16(_p(x), is_bf, ld, rows, cols, _p(out), out.shape[1], _stream()),
+         "fbl_transpose_to_bf16")
+
+
+def colsum_ws(cols, device):
+    return torch.empty(load().fbl_colsum_ws_floats(cols), dtype=torch.float32, device=device)
+
+
+def colsum(x, out, ws, rows=None, cols=None):
+    ld = _rows2d(x, "x")
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    is_bf = 1 if x.dtype == torch.bfloat16 else 0
+    _chk(load().fbl_colsum(_p(x), is_bf, ld, rows, cols, _p(out), _p(ws), _stream()), "fbl_colsum")
+
+
+def head_strides(B, Sp, nh, head_major):
+    """(sh, sb, sd) of a per-head transposed tensor: [B,nh,64,Sp] (head_major=False) or [nh,64,B,Sp] (True)."""
+    if head_major:
+        return 64 * B * Sp, Sp, B * Sp
+    return 64 * Sp, nh * 64 * Sp, Sp
+
+
+def head_transpose(v, vt, B, S, Sp, nh, head_major=False):
+    ldv = _rows2d(v, "v")
+    _req(v, torch.bfloat16, "v"); _req(vt, torch.bfloat16, "vt")
+    assert vt.is_contiguous() and vt.numel() == B * nh * 64 * Sp
+    sh, sb, sd = head_strides(B, Sp, nh, head_major)
+    _chk(load().fbl_head_transpose(_p(v), ldv, _p(vt), B, S, Sp, nh, sh, sb, sd, _stream()), "fbl_head_transpose")
+
+
+def disent_attn_fwd(q, k, vt, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0,
+                    vt_head_major=False):
+    for t, n in ((q, "q"), (k, "k"), (pk, "pk"), (pq, "pq"), (ctx, "ctx"), (vt, "vt")):
+        _req(t, torch.bfloat16, n)
+    _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
+    assert relidx.numel() == 2 * S - 1 and mask.is_contiguous() and vt.is_contiguous()
+    ldq, ldk, ldp, ldo = _rows2d(q, "q"), _rows2d(k, "k"), _rows2d(pk, "pk"), _rows2d(ctx, "ctx")
+    assert _rows2d(pq, "pq") == ldp
+    sh, sb, sd = head_strides(B, Sp, nh, vt_head_major)
+    _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(vt), sh, sb, sd, _p(pk), _p(pq), ldp, _p(relidx),
+                                    _p(mask), float(scale), float(p_drop), int(seed), _p(ctx), ldo, _p(lse), B, S, Sp,
+                                    nh, span2, _stream()), "fbl_disent_attn_fwd")
+
+
+def attn_rowdot(dO, O, out, B, S, nh):
+    ld = _rows2d(dO, "dO")
+    assert _rows2d(O, "O") == ld
+    _chk(load().fbl_attn_rowdot(_p(dO), _p(O), ld, _p(out), B, S, nh, _stream()), "fbl_attn_rowdot")
+
+
+def disent_attn_bwd_ds(q, k, v, dO, dOT, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
+                       p_drop=0.0, seed=0, t_head_major=True):
+    ldq = _rows2d(q, "q")
+    assert _rows2d(k, "k") == ldq and _rows2d(v, "v") == ldq
+    ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
+    assert _rows2d(pq, "pq") == ldp
+    sh, sb, sd = head_strides(B, Sp, nh, t_head_major)
+    _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(dOT), sh, sb, sd, _p(pk), _p(pq), ldp,
+                                       _p(relidx), _p(mask), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
+                                       _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, _stream()),
+         "fbl_disent_attn_bwd_ds")
+
+
+def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True):
+    ldout = _rows2d(out, "out")
+    sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
+    _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(out), ldout,
+                                          _p(GT), B, S, Sp, nh, span2, _stream()), "fbl_disent_attn_bwd_shear")
+
+
+def ce_fwd(logits, labels, V, row_lse, loss_sum_cnt):
+    ldv = _rows2d(logits, "logits")
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels")
+    _chk(load().fbl_ce_fwd(_p(logits), ldv, _p(labels), logits.shape[0], V, _p(row_lse), _p(loss_sum_cnt), _stream()),
+         "fbl_ce_fwd")
+
+
+def ce_bwd_rows(logits, labels, rows, V, Vp, row_lse, loss_sum_cnt, gscale, dlogits):
+    ldv = _rows2d(logits, "logits")
+    _req(rows, torch.int32, "rows")
+    _chk(load().fbl_ce_bwd_rows(_p(logits), ldv, _p(labels), _p(rows), rows.numel(), V, Vp, _p(row_lse),
+                                _p(loss_sum_cnt), float(gscale), _p(dlogits), _stream()), "fbl_ce_bwd_rows")
+
+
+def gather_rows_bf16(x, rows, out):
+    ld = _rows2d(x, "x")
+    _chk(load().fbl_gather_rows_bf16(_p(x), ld, _p(rows), rows.numel(), x.shape[1], _p(out), _stream()),
+         "fbl_gather_rows_bf16")
+
+
+def scatter_rows_f32(x, rows, out):
+    ld = _rows2d(out, "out")
+    _chk(load().fbl_scatter_rows_f32(_p(x), _p(rows), rows.numel(), x.shape[1], _p(out), ld, _stream()),
+         "fbl_scatter_rows_f32")
+
+
+def sumsq(x, out):
+    _chk(load().fbl_sumsq(_p(x), x.numel(), _p(out), _stream()), "fbl_sumsq")
+
+
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0):
+    _chk(load().fbl_adam_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), int(step), _p(sumsq_t), float(max_norm), float(grad_scale),
+                              _stream()), "fbl_adam_flat")
+
+
+def cast_bf16(x, out):
+    _req(x, torch.float32, "x"); _req(out, torch.bfloat16, "out")
+    assert x.is_contiguous() and out.is_contiguous()
+    _chk(load().fbl_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "fbl_cast_f32_to_bf16")
+
+
+def dropout_f32(x, p_drop, seed, out_f32=None, out_bf16=None):
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    _chk(load().fbl_dropout_f32(_p(x), float(p_drop), int(seed), _p(out_f32), _p(out_bf16), x.numel(), _stream()),
+         "fbl_dropout_f32")
+
+
+def dropout_bf16_(x, p_drop, seed):
+    _req(x, torch.bfloat16, "x")
+    assert x.is_contiguous()
+    _chk(load().fbl_dropout_bf16(_p(x), float(p_drop), int(seed), x.numel(), _stream()), "fbl_dropout_bf16")

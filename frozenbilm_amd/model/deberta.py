@@ -1,0 +1,290 @@
+"""MI355X-native DebertaV2ForMaskedLM with video prefix + adapters: drop-in for the reference's
+model/deberta.py:1289-1501 on the masked-LM path.
+
+Same constructor and ``forward`` signature, same ``state_dict`` key names, same freeze policy
+(model/deberta.py:1152-1158, 1334-1339).  Underneath there is no ATen math: ``forward`` runs the explicit HIP pipeline
+of ``frozenbilm_amd.engine`` (C-ABI kernels of libfbl.so on the current HIP stream) and, when gradients are enabled,
+returns a loss whose ``backward()`` runs the explicit backward pipeline (one autograd node for the whole model).
+
+Host-side layout (288 GB HBM: replicate freely):
+  * fp32 masters under the reference parameter names; every TRAINABLE parameter (linear_video, adapters, LayerNorms)
+    is a view into ONE flat fp32 buffer, its gradient a view into one flat grad buffer ordered by backward completion
+    (head LN, layer 23 ... layer 0, conv LN, encoder LN, embeddings) -> fused clip+Adam and bucketed RCCL all-reduce
+    work on contiguous slices.
+  * frozen matrices are packed once to bf16 MFMA operands, both W ([out,in], forward) and W^T (dX = dY.W).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import lib as L
+from .adapter import Adapter  # noqa: F401  (re-export, mirrors `from model.adapter import Adapter`)
+from .config import DebertaV2Config
+
+
+class MaskedLMOutput(dict):
+    """Attribute + item access (`out.loss`, `out["loss"]`), like transformers' MaskedLMOutput (main.py:67)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+
+class _Node(nn.Module):
+    """Bare container used to reproduce the reference's module tree (hence its state_dict key names)."""
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def param_shapes(cfg: DebertaV2Config, features_dim: int, ds_attn: int, ds_ff: int, n_ans: int) -> "OrderedDict[str, tuple]":
+    H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    sh: "OrderedDict[str, tuple]" = OrderedDict()
+    e = "deberta.embeddings"
+    sh[e + ".word_embeddings.weight"] = (V, H)
+    sh[e + ".position_embeddings.weight"] = (cfg.max_position_embeddings, H)
+    sh[e + ".LayerNorm.weight"] = (H,)
+    sh[e + ".LayerNorm.bias"] = (H,)
+    if features_dim:
+        sh[e + ".linear_video.weight"] = (H, features_dim)
+        sh[e + ".linear_video.bias"] = (H,)
+    for i in range(cfg.num_hidden_layers):
+        p = f"deberta.encoder.layer.{i}"
+        for n in ("query_proj", "key_proj", "value_proj"):
+            sh[f"{p}.attention.self.{n}.weight"] = (H, H)
+            sh[f"{p}.attention.self.{n}.bias"] = (H,)
+        sh[p + ".attention.output.dense.weight"] = (H, H)
+        sh[p + ".attention.output.dense.bias"] = (H,)
+        sh[p + ".attention.output.LayerNorm.weight"] = (H,)
+        sh[p + ".attention.output.LayerNorm.bias"] = (H,)
+        if ds_attn:
+            A = H // ds_attn
+            sh[p + ".attention.output.adapter.down.weight"] = (A, H)
+            sh[p + ".attention.output.adapter.down.bias"] = (A,)
+            sh[p + ".attention.output.adapter.up.weight"] = (H, A)
+            sh[p + ".attention.output.adapter.up.bias"] = (H,)
+        sh[p + ".intermediate.dense.weight"] = (I, H)
+        sh[p + ".intermediate.dense.bias"] = (I,)
+        sh[p + ".output.dense.weight"] = (H, I)
+        sh[p + ".output.dense.bias"] = (H,)
+        sh[p + ".output.LayerNorm.weight"] = (H,)
+        sh[p + ".output.LayerNorm.bias"] = (H,)
+        if ds_ff:
+            A = H // ds_ff
+            sh[p + ".output.adapter.down.weight"] = (A, H)
+            sh[p + ".output.adapter.down.bias"] = (A,)
+            sh[p + ".output.adapter.up.weight"] = (H, A)
+            sh[p + ".output.adapter.up.bias"] = (H,)
+    c = "deberta.encoder"
+    sh[c + ".rel_embeddings.weight"] = (2 * cfg.att_span, H)
+    sh[c + ".LayerNorm.weight"] = (H,)
+    sh[c + ".LayerNorm.bias"] = (H,)
+    if cfg.conv_kernel_size > 0:
+        sh[c + ".conv.conv.weight"] = (H, H, cfg.conv_kernel_size)
+        sh[c + ".conv.conv.bias"] = (H,)
+        sh[c + ".conv.LayerNorm.weight"] = (H,)
+        sh[c + ".conv.LayerNorm.bias"] = (H,)
+    h = "lm_predictions.lm_head"
+    sh[h + ".bias"] = (V,)
+    sh[h + ".dense.weight"] = (H, H)
+    sh[h + ".dense.bias"] = (H,)
+    sh[h + ".LayerNorm.weight"] = (H,)
+    sh[h + ".LayerNorm.bias"] = (H,)
+    if n_ans:
+        sh["answer_embeddings.weight"] = (n_ans, H)
+        sh["answer_bias"] = (n_ans,)
+    return sh
+
+
+def flat_order(cfg: DebertaV2Config, names: List[str]) -> List[str]:
+    """Trainable names in backward-completion order (bucket order of the gradient all-reduce)."""
+    def take(prefix):
+        return [n for n in names if n.startswith(prefix)]
+
+    out: List[str] = []
+    out += take("lm_predictions.")
+    for i in reversed(range(cfg.num_hidden_layers)):
+        if i == 0:
+            out += take("deberta.encoder.conv.")
+        out += take(f"deberta.encoder.layer.{i}.")
+    out += take("deberta.encoder.LayerNorm.")
+    out += take("deberta.embeddings.")
+    rest = [n for n in names if n not in set(out)]
+    return out + rest
+
+
+class DebertaV2ForMaskedLM(nn.Module):
+    def __init__(
+        self,
+        config,
+        max_feats=10,
+        features_dim=768,
+        freeze_lm=True,
+        freeze_mlm=True,
+        ds_factor_attn=8,
+        ds_factor_ff=8,
+        ft_ln=True,
+        dropout=0.1,
+        n_ans=0,
+        freeze_last=True,
+    ):
+        super().__init__()
+        self.config = DebertaV2Config.from_any(config)
+        self.config.validate_supported()
+        cfg = self.config
+        for ds in (ds_factor_attn, ds_factor_ff):
+            if ds:
+                assert not cfg.hidden_size % ds  # model/adapter.py:10
+        self.max_feats = max_feats
+        self.features_dim = features_dim
+        self.ds_factor_attn = ds_factor_attn
+        self.ds_factor_ff = ds_factor_ff
+        self.adapter_dropout = float(dropout) if dropout else 0.0
+        self.n_ans = n_ans
+        self.freeze_lm, self.freeze_mlm, self.ft_ln, self.freeze_last = freeze_lm, freeze_mlm, ft_ln, freeze_last
+        if not (freeze_lm and freeze_mlm):
+            raise NotImplementedError(
+                "the MI355X path implements FrozenBiLM's frozen-LM regime (freeze_lm=freeze_mlm=True): "
+                "only linear_video, adapters and LayerNorms receive gradients")
+
+        shapes = param_shapes(cfg, features_dim, ds_factor_attn, ds_factor_ff, n_ans)
+        g = torch.Generator().manual_seed(0)
+        for name, shape in shapes.items():
+            if "LayerNorm" in name:
+                t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            elif name.endswith(".bias") or name == "answer_bias":
+                t = torch.zeros(shape)  # model/deberta.py:1085-1086
+            else:
+                t = torch.randn(shape, generator=g) * cfg.initializer_range  # :1084,1088
+            if name.endswith("word_embeddings.weight"):
+                t[cfg.pad_token_id].zero_()  # :1089-1090
+            self._register(name, nn.Parameter(t, requires_grad=self._trainable(name)))
+        emb = self._module("deberta.embeddings")
+        emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
+        self._engine = None
+        self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
+
+    # ---------------------------------------------------------------- module tree helpers
+    def _module(self, dotted: str) -> nn.Module:
+        m: nn.Module = self
+        for part in dotted.split("."):
+            if part not in m._modules:
+                m.add_module(part, _Node())
+            m = m._modules[part]
+        return m
+
+    def _register(self, name: str, p: nn.Parameter):
+        if "." in name:
+            mod, leaf = name.rsplit(".", 1)
+            self._module(mod).register_parameter(leaf, p)
+        else:
+            self.register_parameter(name, p)
+
+    def _trainable(self, name: str) -> bool:
+        if name.startswith("answer_"):
+            return not self.freeze_last
+        if "linear_video" in name or "adapter" in name:
+            return True
+        return bool(self.ft_ln and "LayerNorm" in name)
+
+    # ---------------------------------------------------------------- reference API
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def get_param(self, name: str) -> torch.Tensor:
+        m: nn.Module = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            m = m._modules[part]
+        return m._parameters[parts[-1]]
+
+    def set_answer_embeddings(self, a2tok, freeze_last=True):
+        """model/deberta.py:1358-1380: answer table = masked mean of the word embeddings of each answer's tokens.
+        (The reference assigns ``answer_bias.weight``, an attribute, so the effective bias keeps its value.)"""
+        E = self.get_param("deberta.embeddings.word_embeddings.weight")
+        pad = self.config.pad_token_id
+        a2tok = a2tok.to(E.device)
+        keep = (a2tok != pad)
+        table = (E.data[a2tok] * keep.float()[:, :, None]).sum(1) / keep.sum(1, keepdim=True).clamp(min=1)
+        if len(table) != self.n_ans or "answer_embeddings" not in self._modules:
+            assert not self.training
+            self.n_ans = len(table)
+            self._register("answer_embeddings.weight", nn.Parameter(table.clone(), requires_grad=False))
+            old = self._parameters.get("answer_bias")
+            self.register_parameter("answer_bias", nn.Parameter(torch.zeros(self.n_ans, device=E.device), requires_grad=False))
+            del old
+        else:
+            self.get_param("answer_embeddings.weight").data = table
+        self.freeze_last = freeze_last
+        self.get_param("answer_embeddings.weight").requires_grad_(False)
+        self.get_param("answer_bias").requires_grad_(False)
+        self.invalidate()
+
+    def invalidate(self):
+        """Drop the packed bf16 operands / flat buffers (after load_state_dict, .to(), set_answer_embeddings)."""
+        self._engine = None
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self.invalidate()
+        # tolerate the reference-only keys (untied decoder copy, buffers)
+        sd = {k: v for k, v in state_dict.items() if "lm_head.decoder" not in k}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        if self._engine is None:
+            from ..engine import Engine
+
+            self._engine = Engine(self)
+        return self._engine
+
+    def forward(
+        self,
+        input_ids=None,
+        attention_mask=None,
+        token_type_ids=None,
+        position_ids=None,
+        inputs_embeds=None,
+        labels=None,
+        output_attentions=None,
+        return_dict=None,
+        video=None,
+        video_mask=None,
+        mlm=False,
+        output_hidden_states=False,
+    ):
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None:
+            if inputs_embeds is not None:
+                raise NotImplementedError("inputs_embeds is not on the FrozenBiLM hot path")
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        if output_attentions:
+            raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
+        eng = self.engine()
+        res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states)
+        out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
+                             attentions=None)
+        if return_dict is False:
+            return tuple(v for v in (out["loss"], out["logits"], out["hidden_states"]) if v is not None)
+        return out

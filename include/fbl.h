@@ -1,0 +1,174 @@
+/* libfbl -- C ABI of the MI355X (gfx950) kernels behind FrozenBiLM's masked-LM hot path.
+ *
+ * The reference (antoyang/FrozenBiLM) has no FFI: its hot path is stock ATen ops called from
+ * model/deberta.py + model/adapter.py.  This header is therefore the boundary the build inserts BELOW the
+ * reference's Python call boundary: every entry point replaces a group of ATen calls, cited
+ * per function as "ref: file:line".  Conventions:
+ *   - extern "C", plain device pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*.
+ *   - every function only enqueues work on `stream` (graph-capturable: no malloc/free/sync inside) and returns
+ *     0 on success, a positive hipError_t, or a negative FBL_ERR_* code for argument errors.
+ *   - bf16 tensors are raw uint16 storage (torch.bfloat16), fp32 are float, indices int64/int32 as stated.
+ *   - row-major; `ld*` are row strides in ELEMENTS.
+ */
+#ifndef FBL_H
+#define FBL_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBL_ERR_SHAPE (-1)
+#define FBL_ERR_ALIGN (-2)
+#define FBL_ERR_ARG (-3)
+
+enum { FBL_ACT_NONE = 0, FBL_ACT_GELU = 1, FBL_ACT_RELU = 2 };
+enum {
+  FBL_AUX_NONE = 0,
+  FBL_AUX_ADD_F32 = 1,        /* out = act(..) + aux_f32[m,n]                       (residual / grad accumulate) */
+  FBL_AUX_ADD_BF16 = 2,       /* out = act(..) + aux_bf16[m,n]                                                    */
+  FBL_AUX_MUL_DGELU_BF16 = 3, /* out = (..) * gelu'(aux_bf16[m,n])   (backward of deberta.py:310-313)            */
+  FBL_AUX_MUL_POS_BF16 = 4    /* out = (..) * (aux_bf16[m,n] > 0)    (backward of adapter.py:39 ReLU[+dropout])  */
+};
+
+int fbl_abi_version(void);
+
+/* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
+ * epi: v = alpha*acc + bias[n]; v *= rowscale[m]; pre = v; v = act(v); v = aux-op(v); -> out_f32 / out_bf16 (/ out_pre).
+ * batch > 1: strided batch (strides in elements).  splitk > 1: atomicAdd of partial products into out_f32.
+ * ref: every nn.Linear on the path -- model/deberta.py:255,311,329,757-765,847-853,994,1545,1550;
+ *      model/adapter.py:38,42; conv1d deberta.py:397 (as K=3H GEMM); and their autograd dX/dW. */
+int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
+                     const float* rowscale, float alpha, int act, int aux_kind, const void* aux, int64_t ld_aux,
+                     float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
+                     int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
+                     void* stream);
+
+/* t0[b, s, :] = s < T ? vproj[b*T + s, :] : E[ids[b, s-T], :]     (fp32).  vproj may be NULL (T = 0).
+ * ref: model/deberta.py:1012-1016 (word_embeddings + cat with linear_video output). */
+int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H, float* out_t,
+                     void* stream);
+
+/* Fused  t = dropout(y) + residual ;  out = LayerNorm(t) * gamma + beta [* rowmask]     (one wave per row).
+ *  y: fp32 [N, ldy] or NULL.  dropout: p in [0,1), element (row*H+col) keyed by `seed` (counter-based, regenerated in bwd).
+ *  residual, either  r_plain fp32 [N,H]  or the "normalised form" of a previous LayerNorm output:
+ *     (r_t - mean)*rstd*r_gamma + r_beta [* r_rowmask]  with (mean,rstd) = r_stats[row*2..]  -- the fp32 residual stream
+ *     is never materialised, only t and the row statistics are.
+ *  writes out_t fp32 [N,H] (pre-LN, saved for backward), out_stats fp32 [N,2], out_bf16 [N,H] (GEMM operand),
+ *  out_f32 optional.  H % 64 == 0, H <= 2048.
+ * ref: model/deberta.py:258-259, 332-333 (dropout + residual + LayerNorm), :1043-1054 (embeddings), :405-417 (conv). */
+int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const float* r_plain, const float* r_t,
+               const float* r_stats, const float* r_gamma, const float* r_beta, const int32_t* r_rowmask,
+               const float* gamma, const float* beta, float eps, const int32_t* rowmask, float* out_t,
+               float* out_stats, void* out_bf16, float* out_f32, int N, int H, void* stream);
+
+/* out = LN-normalised-form(t, stats, gamma, beta)[*rowmask] + add_bcast[row % S]  -> fp32 and/or bf16.
+ * ref: model/deberta.py:1392 (z_states += hidden_states) and materialising hidden_states on request. */
+int fbl_ln_materialize(const float* t, const float* stats, const float* gamma, const float* beta,
+                       const int32_t* rowmask, const float* add_bcast, int S, float* out_f32, void* out_bf16, int N,
+                       int H, void* stream);
+
+/* Backward of fbl_ln_fwd.  dout fp32 [N,H] = grad of the LN output (after rowmask).
+ *  out_dt fp32 [N,H]: grad wrt t (= grad of the residual branch).  out_dy_bf16/out_dy_f32: grad wrt y (dropout mask
+ *  regenerated from seed), optional.  dgamma/dbeta [H] are ACCUMULATED (+=) deterministically via `ws`
+ *  (fp32 workspace of fbl_ln_bwd_ws_floats(H) floats).
+ * ref: autograd of torch.nn.LayerNorm + XDropout.backward (model/deberta.py:185-190). */
+int64_t fbl_ln_bwd_ws_floats(int H);
+int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats, const float* gamma,
+               float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16, float* out_dy_f32, float* dgamma,
+               float* dbeta, float* ws, int N, int H, void* stream);
+
+/* out[n, k*H + c] = x[b, s+k-1, c] (0 outside the sequence), n = b*S+s, k in {0,1,2}: im2col for the 3-tap conv.
+ * ref: model/deberta.py:396-400 (Conv1d k=3 pad=1 over the sequence axis). */
+int fbl_im2col3(const void* x_bf16, void* out_bf16, int B, int S, int H, void* stream);
+/* backward of im2col3: dx[b,s,c] (+)= sum_k dcol[b, s-k+1, k*H + c]   (fp32 in, fp32 out, accumulate flag) */
+int fbl_col2im3(const float* dcol, float* dx, int B, int S, int H, int accumulate, void* stream);
+
+/* y = gelu(dropout(c)) elementwise, fp32 -> fp32 (+ optional bf16).  ref: model/deberta.py:403. */
+int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, float* out_f32, int64_t n, void* stream);
+/* dc = dy * gelu'(dropout(c)) * dropscale ; writes bf16 (GEMM operand) */
+int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, void* out_bf16, float* out_f32,
+                         int64_t n, void* stream);
+
+/* out_bf16[c, r] = in[r, c] for r < rows, 0 for rows <= r < rows_pad; in is fp32 (in_is_bf16=0) or bf16.
+ * Produces the K-contiguous operands of the dW = X^T.dY contractions (contraction over rows). */
+int fbl_transpose_to_bf16(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, void* out_bf16,
+                          int64_t rows_pad, void* stream);
+
+/* out[c] += sum_r in[r, c]  (bias gradients).  in fp32 or bf16.  ws: fbl_colsum_ws_floats(cols) floats. */
+int64_t fbl_colsum_ws_floats(int cols);
+int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, float* out, float* ws,
+               void* stream);
+
+/* Per-head transpose: vt[h*out_sh + b*out_sb + d*out_sd + s] = V[b*S+s, h*64+d] (s < S), 0 for S <= s < Sp.
+ * V has row stride ldv (e.g. 3H inside the fused QKV buffer).  Gives the P.V / dS.K / dS^T.Q MFMAs their
+ * position-contiguous operands; with (sh, sd, sb) = (64*B*Sp, B*Sp, Sp) the rows are also the K-contiguous operands of
+ * the per-head position-table gradient GEMMs. */
+int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, int S, int Sp, int nh, int64_t out_sh,
+                       int64_t out_sb, int64_t out_sd, void* stream);
+
+/* Fused disentangled self-attention forward (one launch per layer execution):
+ *   score[i,j] = scale*(Q_i.K_j + Q_i.PK[idx(i-j)] + K_j.PQ[idx(i-j)]),  masked softmax (masked -> 0, fully masked
+ *   rows -> 0), attention-prob dropout, ctx = P.V.   head_dim = 64, S <= 512.
+ *   q/k: bf16 rows b*S+s, head h at column h*64 (strides ldq/ldk); vt from fbl_head_transpose (strides v_*);
+ *   pk/pq bf16 [2*span, ldp]; relidx int16 [2S-1]: relidx[d+S-1] = clamp(bucket(d)+span, 0, 2span-1);
+ *   mask int32 [B,S]; out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
+ * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
+int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
+                        int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
+                        const int32_t* mask, float scale, float p_drop, uint64_t seed, void* ctx, int64_t ldo,
+                        float* lse, int B, int S, int Sp, int nh, int span2, void* stream);
+
+/* Backward of fbl_disent_attn_fwd, three launches (ref: autograd of model/deberta.py:717-947, XSoftmax.backward
+ * :134-138, XDropout.backward :185-190):
+ *  fbl_attn_rowdot:            Dv[b,h,i] = dO_i . O_i  (per head).
+ *  fbl_disent_attn_bwd_ds:     recomputes P; writes dV (bf16, into a row-major buffer), dS and dS^T (bf16 [B,nh,Sp,Sp],
+ *                              dS = P*(dP - Dv)*scale, exactly 0 where masked / padded).
+ *  fbl_disent_attn_bwd_shear:  neg=0: out = dQ = dS.K + G1.PK,  G1[i,r] = sum_{j: idx(i-j)=r} dS[i,j]
+ *                              neg=1: out = dK = dS^T.Q + G2.PQ, G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]
+ *                              X = dS / dS^T; YT = transposed K / Q (fbl_head_transpose strides); PT = transposed
+ *                              PK / PQ [nh][64][span2]; also writes GT = G^T as bf16 [nh][span2][B][Sp], the operand of
+ *                              the position-table gradient GEMM  dPK[h] = G1T[h] . QT[h]^T  (dPQ: G2T, KT). */
+int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
+int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
+                           const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
+                           int64_t ldp, const int16_t* relidx, const int32_t* mask, const float* lse, const float* Dv,
+                           float scale, float p_drop, uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B,
+                           int S, int Sp, int nh, int span2, void* stream);
+int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
+                              const void* PT, const int16_t* relidx, void* out, int64_t ldout, void* GT, int B, int S,
+                              int Sp, int nh, int span2, void* stream);
+
+/* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
+ * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */
+int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* labels, int N, int V, float* row_lse,
+               float* loss_sum_cnt, void* stream);
+/* dlogits_bf16[r, :] = (softmax(logits[rows[r]]) - onehot) * gscale[0]/count, zero-padded to Vp columns;
+ * rows int32 [R] = indices of labelled rows. */
+int fbl_ce_bwd_rows(const float* logits, int64_t ldv, const int64_t* labels, const int32_t* rows, int R, int V,
+                    int Vp, const float* row_lse, const float* loss_sum_cnt, float gscale, void* dlogits_bf16,
+                    void* stream);
+
+/* gathers rows: out_bf16[r, :] = in_bf16[rows[r], :] ; scatter-add fp32: out[rows[r], :] += in[r, :] */
+int fbl_gather_rows_bf16(const void* in, int64_t ld, const int32_t* rows, int R, int cols, void* out, void* stream);
+int fbl_scatter_rows_f32(const float* in, const int32_t* rows, int R, int cols, float* out, int64_t ld, void* stream);
+
+/* Fused multi-tensor Adam over ONE flat fp32 buffer (all trainable params are views into it) with the global-norm
+ * clip folded in: g *= min(1, max_norm/(norm+1e-6)) where norm = sqrt(sumsq[0]).
+ * ref: main.py:82-84 (clip_grad_norm_ + torch.optim.Adam.step, betas (0.9,0.95), eps 1e-8, wd 0). */
+int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, void* stream); /* out[0] += sum x^2 */
+int fbl_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale,
+                  void* stream);
+
+/* elementwise helpers */
+int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* counter-based dropout (element i keyed by seed): fp32 in -> fp32 and/or bf16 out (in-place allowed);
+ * bf16 in place.  ref: StableDropout / XDropout model/deberta.py:171-217, nn.Dropout model/adapter.py:41. */
+int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, float* out_f32, void* out_bf16, int64_t n,
+                    void* stream);
+int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,205 @@
+"""Model-level parity on a real MI355X: the HIP pipeline (through the reference-shaped Python boundary) against the
+golden vectors captured from the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (bf16 MFMA operands, fp32 accumulation / residual stream): logits max-abs <= 5e-2 (BASELINE north_star),
+loss <= 2e-2 abs, trainable gradients <= 6% of each tensor's max (bf16 operand rounding through a 3..24-layer chain),
+integer outputs (top-k ids on well separated logits) exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import deberta_oracle as O  # noqa: E402
+from tests.golden.make_goldens import _tiny_cfg, synth_batch  # noqa: E402
+from tests.gpu_refs import stats  # noqa: E402
+
+DEV = "cuda"
+
+
+def build(cfg: O.OracleConfig, P, train=False):
+    from frozenbilm_amd.model.config import DebertaV2Config
+    from frozenbilm_amd.model.deberta import DebertaV2ForMaskedLM
+
+    c = DebertaV2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                        max_position_embeddings=cfg.max_position_embeddings, position_buckets=cfg.position_buckets,
+                        layer_norm_eps=cfg.layer_norm_eps, conv_kernel_size=cfg.conv_kernel_size)
+    m = DebertaV2ForMaskedLM(c, max_feats=cfg.max_feats, features_dim=cfg.features_dim, ds_factor_attn=cfg.ds_factor_attn,
+                             ds_factor_ff=cfg.ds_factor_ff, n_ans=cfg.n_ans)
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in k for k in missing), missing
+    m.to(DEV)
+    m.train(train)
+    return m
+
+
+def to_dev(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+def test_tiny_forward_golden(golden):
+    g = golden("G5_tiny_model")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    with torch.no_grad():
+        out = m(**to_dev(batch), output_hidden_states=True)
+    hs = torch.stack([h.float().cpu() for h in out.hidden_states], 0)
+    print(stats("hidden_states", hs, g["hidden_states"]))
+    print(stats("logits", out.logits.cpu(), g["logits"]))
+    err_h = (hs - g["hidden_states"]).abs().max().item()
+    assert err_h < 5e-2, err_h
+    assert (out.logits.cpu() - g["logits"]).abs().max().item() < 5e-2
+    assert abs(out.loss.item() - g["loss"].item()) < 2e-2
+    assert out["loss"] is out.loss  # item + attribute access like MaskedLMOutput
+
+
+def test_tiny_text_only_golden(golden):
+    g5, gb = golden("G5_tiny_model"), golden("G5b_tiny_textonly")
+    cfg = _tiny_cfg()
+    m = build(cfg, O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1))
+    with torch.no_grad():
+        out = m(input_ids=g5["in.input_ids"].to(DEV), attention_mask=g5["in.attention_mask"].to(DEV))
+    assert out.logits.shape == gb["logits"].shape
+    assert (out.logits.cpu() - gb["logits"]).abs().max().item() < 5e-2
+
+
+def test_tiny_backward_golden(golden):
+    g = golden("G5_tiny_model")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)  # eval mode: dropout off, gradients on (the reference goldens were taken the same way)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    out = m(**to_dev(batch))
+    out.loss.backward()
+    bad = []
+    n = 0
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        ref = g["grad." + name]
+        n += 1
+        got = p.grad.float().cpu()
+        rel = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        if rel > 6e-2:
+            bad.append((name, rel, ref.abs().max().item()))
+    assert n == len([k for k in g if k.startswith("grad.")])
+    assert not bad, bad
+    # a second backward accumulates (p.grad += ...), zero_grad(set_to_none) resets
+    g1 = {nm: p.grad.clone() for nm, p in m.named_parameters() if p.requires_grad}
+    out2 = m(**to_dev(batch))
+    out2.loss.backward()
+    for nm, p in m.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p.grad, 2 * g1[nm], rtol=1e-3, atol=1e-6), nm
+    m.zero_grad(set_to_none=True)
+    m(**to_dev(batch)).loss.backward()
+    for nm, p in m.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p.grad, g1[nm], rtol=1e-3, atol=1e-6), nm
+
+
+def test_answer_head_golden(golden):
+    g = golden("G9_answers")
+    cfg = _tiny_cfg(n_ans=50)
+    P = O.synth_params(cfg, seed=9, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    m.set_answer_embeddings(g["a2tok"].to(DEV))
+    assert torch.allclose(m.get_param("answer_embeddings.weight").cpu(), g["answer_embeddings"], atol=1e-6)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    with torch.no_grad():
+        out = m(**to_dev(batch))
+    lg = out.logits.float().cpu()
+    assert lg.shape == g["logits"].shape
+    assert (lg - g["logits"]).abs().max().item() < 5e-2
+    # top-1 answer ids: exact wherever the reference's top-2 margin exceeds the tolerance
+    ref_sorted = g["logits"].sort(-1, descending=True).values
+    clear = (ref_sorted[..., 0] - ref_sorted[..., 1]) > 0.1
+    assert torch.equal(lg.argmax(-1)[clear], g["top10"][..., 0][clear])
+
+
+def test_ragged_lengths_vs_oracle():
+    """S not a multiple of 16/64, empty video rows, padded text: bf16 path vs the fp32 CPU oracle."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=21, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    for (B, Lt, seed) in ((1, 1, 1), (2, 60, 2), (5, 131, 3)):
+        batch = synth_batch(cfg, B=B, L=Lt, seed=seed) if Lt > 2 else dict(
+            video=torch.randn(1, 10, cfg.features_dim), video_mask=torch.zeros(1, 10, dtype=torch.long),
+            input_ids=torch.tensor([[7]]), attention_mask=torch.ones(1, 1, dtype=torch.long), labels=torch.tensor([[7]]))
+        with torch.no_grad():
+            ref = O.forward(P, cfg, **batch)
+            out = m(**to_dev(batch))
+        err = (out.logits.cpu() - ref["logits"]).abs().max().item()
+        assert err < 5e-2, (B, Lt, err)
+        assert abs(out.loss.item() - ref["loss"].item()) < 2e-2
+
+
+def test_sequence_limit_error():
+    cfg = _tiny_cfg()
+    m = build(cfg, O.synth_params(cfg, seed=1, std=0.05))
+    ids = torch.ones(1, 503, dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError):
+        m(input_ids=ids, attention_mask=torch.ones_like(ids), video=torch.zeros(1, 10, cfg.features_dim, device=DEV))
+    with pytest.raises(ValueError):
+        m()
+
+
+def test_train_mode_dropout_and_step():
+    """train(): counter-based dropout is live (outputs differ from eval, differ step to step), loss finite, an
+    optimizer step changes only trainable parameters and lowers the loss on a repeated batch."""
+    from frozenbilm_amd.optim import FusedAdam
+
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=31, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P, train=True)
+    batch = to_dev(synth_batch(cfg, B=4, L=40, seed=5))
+    frozen_before = m.get_param("deberta.encoder.layer.0.intermediate.dense.weight").clone()
+    opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.95))
+    l0 = m(**batch).loss
+    l1 = m(**batch).loss
+    assert torch.isfinite(l0) and l0.item() != l1.item()
+    m.eval()
+    with torch.no_grad():
+        le0 = m(**batch).loss.item()
+    m.train()
+    for _ in range(8):
+        opt.zero_grad()
+        loss = m(**batch).loss
+        loss.backward()
+        opt.step(clip_max_norm=1.0)
+    m.eval()
+    with torch.no_grad():
+        le1 = m(**batch).loss.item()
+    assert le1 < le0, (le0, le1)
+    assert torch.equal(frozen_before, m.get_param("deberta.encoder.layer.0.intermediate.dense.weight"))
+
+
+@pytest.mark.slow
+def test_xlarge_golden(golden):
+    """True DeBERTa-v2-XLarge dims, seeded weights (regenerated bit-identically on this box), B=2, S=266."""
+    g = golden("G6_xlarge")
+    cfg = O.OracleConfig()
+    P = O.synth_params(cfg, seed=0)
+    m = build(cfg, P)
+    del P
+    batch = synth_batch(cfg, B=2, L=256, seed=66)
+    with torch.no_grad():
+        out = m(**to_dev(batch))
+    lg = out.logits
+    sl = lg[:, ::19, ::997].float().cpu()
+    print(stats("xlarge logits slice", sl, g["logits_slice"]))
+    err = (sl - g["logits_slice"]).abs()
+    row0 = (lg[0, 12, :2048].float().cpu() - g["logits_row0"]).abs()
+    print("row0 max err", row0.max().item(), "loss", out.loss.item(), "ref", g["loss"].item())
+    # north_star: logits within 5e-2 (bf16); SURVEY section 7 notes a naive mixed-precision run only meets it at p99.9
+    assert err.max().item() < 5e-2 and row0.max().item() < 5e-2
+    assert abs(out.loss.item() - g["loss"].item()) < 2e-2
+    agree = (lg.argmax(-1).cpu() == g["argmax"]).float().mean().item()
+    print("argmax agreement", agree)
+    assert agree > 0.93
