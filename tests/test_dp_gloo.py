@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange (parallel.GradReducer) and the dist helpers."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frozenbilm_amd.parallel import GradReducer
+        from frozenbilm_amd.util import dist as D
+
+        n = 5000
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(n, generator=g)
+        mine = flat.clone()
+        ends = {"head": 16, "layer2": 1800, "layer1": 3600, "conv": 3616, "layer0": 4900, "relln": 4916, "emb": n}
+        red = GradReducer(flat, ends, min_bucket_elems=64)
+        for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
+            red.ready(key)
+        red.finish()
+        others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        expect = sum(others) / world
+        ok = torch.allclose(flat, expect, atol=1e-6)
+        # buckets: contiguous, ordered, covering; tiny ones coalesced into the next
+        spans = red.last_launched
+        ok &= spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        ok &= all(e - s >= 64 for s, e in spans)
+        # second step reuses the reducer
+        flat.copy_(mine)
+        for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
+            red.ready(key)
+        red.finish()
+        ok &= torch.allclose(flat, expect, atol=1e-6)
+        rd = D.reduce_dict({"b": torch.tensor(float(rank)), "a": torch.tensor(10.0 + rank)})
+        ok &= abs(rd["a"].item() - 10.5) < 1e-6 and abs(rd["b"].item() - 0.5) < 1e-6
+        gathered = D.all_gather({"rank": rank, "payload": list(range(rank + 3))})
+        ok &= [x["rank"] for x in gathered] == list(range(world)) and len(gathered[1]["payload"]) == 4
+        ok &= D.get_world_size() == world and D.get_rank() == rank and D.is_main_process() == (rank == 0)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_and_dist_helpers_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)], res
+
+
+def test_single_process_is_identity():
+    from frozenbilm_amd.parallel import GradReducer
+    from frozenbilm_amd.util import dist as D
+
+    flat = torch.arange(10.0)
+    red = GradReducer(flat, {"a": 4, "b": 10}, min_bucket_elems=1)
+    red.ready("a"); red.ready("b"); red.finish()
+    assert torch.equal(flat, torch.arange(10.0)) and red.last_launched == [(0, 4), (4, 10)]
+    d = {"x": torch.tensor(1.0)}
+    assert D.reduce_dict(d) is d and D.all_gather(3) == [3]

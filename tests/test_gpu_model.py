@@ -85,9 +85,12 @@ def test_tiny_backward_golden(golden):
         ref = g["grad." + name]
         n += 1
         got = p.grad.float().cpu()
-        rel = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
-        if rel > 6e-2:
-            bad.append((name, rel, ref.abs().max().item()))
+        # bf16 vs fp32 flips a few ReLU gates of the adapters (pre-activations near 0); with only 111 rows a single
+        # flip moves one row of dW by ~10 %, so the check is norm-based with a loose element-wise cap.
+        fro = (got - ref).norm().item() / max(ref.norm().item(), 1e-9)
+        rel = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        if fro > 6e-2 or rel > 0.3:
+            bad.append((name, round(fro, 4), round(rel, 4)))
     assert n == len([k for k in g if k.startswith("grad.")])
     assert not bad, bad
     # a second backward accumulates (p.grad += ...), zero_grad(set_to_none) resets
@@ -102,6 +105,30 @@ def test_tiny_backward_golden(golden):
     for nm, p in m.named_parameters():
         if p.requires_grad:
             assert torch.allclose(p.grad, g1[nm], rtol=1e-3, atol=1e-6), nm
+
+
+def test_backward_vs_oracle_larger_batch():
+    """N = 8 x 130 rows: gate-flip noise averages out (~1/sqrt(N)); a systematic backward bug would not."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = synth_batch(cfg, B=8, L=120, seed=7)
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    ref = O.forward(P, cfg, **batch)
+    ref["loss"].backward()
+    out = m(**to_dev(batch))
+    out.loss.backward()
+    assert abs(out.loss.item() - ref["loss"].item()) < 2e-2
+    worst = []
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            r = P[name].grad
+            fro = (p.grad.float().cpu() - r).norm().item() / max(r.norm().item(), 1e-9)
+            worst.append((round(fro, 4), name))
+    worst.sort(reverse=True)
+    print("worst relative Frobenius grad errors:", worst[:6])
+    assert worst[0][0] < 4e-2, worst[:6]
 
 
 def test_answer_head_golden(golden):

@@ -1,0 +1,135 @@
+"""CPU: host-side logic of the product (integer tables, masking, schedules, parameter bookkeeping) against the golden
+vectors from the reference -- bit exact for the integer work."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM, build_model
+from frozenbilm_amd.model.deberta import MaskedLMOutput, flat_order, param_shapes
+from frozenbilm_amd.model.relpos import bucket_of_delta, rel_index_vector
+from frozenbilm_amd.util import misc
+from oracle import deberta_oracle as O
+
+
+@pytest.mark.parametrize("S", [1, 2, 74, 129, 266, 512])
+def test_relpos_bit_exact(golden, S):
+    g = golden("G2_relpos")
+    col, row = g[f"col_{S}"].numpy(), g[f"row_{S}"].numpy()
+    d = np.arange(S)
+    assert (bucket_of_delta(d, 256, 512) == col).all()
+    assert (bucket_of_delta(-d, 256, 512) == row).all()
+    v = rel_index_vector(S, 256, 512, 256)
+    assert v.dtype == np.int16 and v.shape == (2 * S - 1,)
+    assert (v[S - 1:] == np.clip(col + 256, 0, 511)).all()
+    assert (v[:S][::-1] == np.clip(row + 256, 0, 511)).all()
+    assert (v == O.rel_index_by_delta(S, O.OracleConfig())).all()
+
+
+class Tok:
+    mask_token = "[MASK]"
+    _pad_token = "[PAD]"
+    pad_token_id = 0
+
+    def __len__(self):
+        return 1000
+
+    def get_special_tokens_mask(self, val, already_has_special_tokens=True):
+        return [1 if v in (1, 2) else 0 for v in val]
+
+    def convert_tokens_to_ids(self, t):
+        return 4
+
+
+def test_mask_tokens_get_mask_lr_bit_exact(golden):
+    g = golden("G7_misc")
+    assert torch.equal(misc.get_mask(g["video_len"], 10), g["get_mask"])
+    assert misc.get_mask(g["video_len"], 10).dtype == torch.int64
+    for seed in (0, 1):
+        ids = g[f"ids_{seed}"].clone()
+        torch.manual_seed(seed)
+        inp, lab = misc.mask_tokens(ids, Tok(), 0.15)
+        assert inp is ids  # in place, like the reference
+        assert torch.equal(inp, g[f"inputs_{seed}"]) and torch.equal(lab, g[f"labels_{seed}"])
+    lrs = []
+    for sched in ("", "linear_with_warmup"):
+        a = types.SimpleNamespace(lr=3e-4, schedule=sched, fraction_warmup_steps=0.1)
+        for step in (0, 1, 9, 10, 11, 50, 99, 100):
+            o = types.SimpleNamespace(param_groups=[{"lr": 0.0}])
+            misc.adjust_learning_rate(o, step, 100, a)
+            lrs.append(o.param_groups[0]["lr"])
+    assert np.array_equal(np.array(lrs), g["lrs"].numpy())
+    t = Tok()
+    t.mask_token = None
+    with pytest.raises(ValueError):
+        misc.mask_tokens(torch.ones(1, 3, dtype=torch.long), t, 0.15)
+
+
+def test_parameter_names_freeze_policy_and_flat_order():
+    cfg = DebertaV2Config()
+    sh = param_shapes(cfg, 1024, 8, 8, 0)
+    osh = O.param_shapes(O.OracleConfig())
+    assert dict(sh) == dict(osh)  # reference state_dict layout
+    trainable = [n for n in sh if O.is_trainable(n)]
+    assert sum(math.prod(sh[n]) for n in trainable) == 30128640
+    assert len(trainable) == 298
+    order = flat_order(cfg, trainable)
+    assert sorted(order) == sorted(trainable) and len(set(order)) == len(order)
+    # backward-completion order: head LN, layer 23 ... layer 1, conv, layer 0, rel LN, embeddings
+    first = lambda pre: min(i for i, n in enumerate(order) if n.startswith(pre))
+    assert first("lm_predictions.") < first("deberta.encoder.layer.23.") < first("deberta.encoder.layer.1.")
+    assert first("deberta.encoder.layer.1.") < first("deberta.encoder.conv.") < first("deberta.encoder.layer.0.")
+    assert first("deberta.encoder.layer.0.") < first("deberta.encoder.LayerNorm") < first("deberta.embeddings.")
+
+
+def test_tiny_model_module_tree_and_errors():
+    c = DebertaV2Config(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    m = DebertaV2ForMaskedLM(c, features_dim=32)
+    names = dict(m.named_parameters())
+    assert "deberta.encoder.layer.1.attention.output.adapter.down.weight" in names
+    assert "deberta.embeddings.position_ids" in m.state_dict()
+    for n, p in names.items():
+        assert p.requires_grad == O.is_trainable(n), n
+    assert names["deberta.embeddings.word_embeddings.weight"][0].abs().sum() == 0  # padding row zeroed
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(input_ids=torch.ones(1, 3, dtype=torch.long))
+    with pytest.raises(ValueError):
+        m()
+    with pytest.raises(ValueError):
+        m(input_ids=torch.ones(1, 3, dtype=torch.long), inputs_embeds=torch.zeros(1, 3, 128))
+    with pytest.raises(NotImplementedError):
+        DebertaV2ForMaskedLM(DebertaV2Config(hidden_size=1024, num_attention_heads=8), features_dim=32)  # head_dim 128
+    with pytest.raises(NotImplementedError):
+        DebertaV2ForMaskedLM(c, features_dim=32, freeze_lm=False)
+    args = types.SimpleNamespace(model_name="deberta-v2-xlarge", features_dim=32, max_feats=10, ds_factor_attn=8,
+                                 ds_factor_ff=0, dropout=0.1, use_video=True)
+    m2 = build_model(args, config=c)
+    assert not any("output.adapter" in n and "attention" not in n for n, _ in m2.named_parameters())
+
+
+def test_masked_lm_output_access():
+    o = MaskedLMOutput(loss=1, logits=2, hidden_states=None, attentions=None)
+    assert o.loss == 1 and o["logits"] == 2 and o[0] == 1 and o[1] == 2
+    with pytest.raises(AttributeError):
+        o.nope
+
+
+@pytest.mark.slow
+def test_oracle_xlarge_golden(golden):
+    """The oracle at true DeBERTa-v2-XLarge dims against the reference's own output (G6)."""
+    from tests.golden.make_goldens import synth_batch
+
+    g = golden("G6_xlarge")
+    cfg = O.OracleConfig()
+    P = O.synth_params(cfg, seed=0)
+    batch = synth_batch(cfg, B=2, L=256, seed=66)
+    with torch.no_grad():
+        out = O.forward(P, cfg, **batch)
+    lg = out["logits"]
+    assert (lg[:, ::19, ::997] - g["logits_slice"]).abs().max().item() < 1e-3
+    assert abs(out["loss"].item() - g["loss"].item()) < 1e-4
+    assert abs(lg.double().sum().item() - g["logits_sum"].item()) < 1e-3 * g["logits_abs_sum"].item() * 1e-3 + 5.0
+    assert torch.equal(lg.argmax(-1), g["argmax"])
+    assert torch.equal(lg.topk(5, -1).indices[:, ::7], g["top5"])
