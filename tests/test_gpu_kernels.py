@@ -351,6 +351,44 @@ def test_adam_and_sumsq(L):
     close(p, pt.detach(), 1e-5, 1e-6, "adam+clip")
 
 
+@pytest.mark.parametrize("H,ds,N", [(128, 8, 1000), (1536, 8, 700)])
+def test_adapter_module_gate_matched(L, H, ds, N):
+    """frozenbilm_amd.model.Adapter (fwd + bwd through the C ABI) vs torch autograd fed the SAME bf16-rounded
+    operands, so both sides open exactly the same ReLU gates (ref: model/adapter.py:33-45)."""
+    from frozenbilm_amd.model import Adapter
+
+    torch.manual_seed(0)
+    ad = Adapter(ds, H, dropout=0.1).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in ad.parameters():
+            p_.copy_(bf(rnd(*p_.shape, seed=p_.numel() % 97, scale=0.05)))
+        ad.down.bias.copy_(rnd(H // ds, seed=5, scale=0.05))
+        ad.up.bias.copy_(rnd(H, seed=6, scale=0.05))
+    x = bf(rnd(N, H, seed=1)).requires_grad_(True)
+    y = ad(x)
+    gy = bf(rnd(N, H, seed=2))
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    wd, bd = ad.down.weight.detach().clone().requires_grad_(True), ad.down.bias.detach().clone().requires_grad_(True)
+    wu, bu = ad.up.weight.detach().clone().requires_grad_(True), ad.up.bias.detach().clone().requires_grad_(True)
+    z = bf(torch.relu(F.linear(xr, wd, bd)))  # the kernel stores z in bf16
+    zr = torch.relu(F.linear(xr, wd, bd))
+    zz = zr + (z - zr).detach()
+    yr = xr + F.linear(zz, wu, bu)
+    yr.backward(gy)
+    close(y, yr, 1e-3, 1e-3, "adapter y")
+    sc = lambda t: t.abs().max().item()
+    close(x.grad, xr.grad, 2e-2, 1e-2 * sc(xr.grad), "dx")
+    close(ad.up.weight.grad, wu.grad, 2e-2, 1e-2 * sc(wu.grad), "dWu")
+    close(ad.up.bias.grad, bu.grad, 1e-2, 1e-2 * sc(bu.grad), "dbu")
+    close(ad.down.weight.grad, wd.grad, 2e-2, 2e-2 * sc(wd.grad), "dWd")
+    close(ad.down.bias.grad, bd.grad, 2e-2, 2e-2 * sc(bd.grad), "dbd")
+    # train mode: dropout on z is live and consistent between forward and backward
+    ad.train()
+    y2 = ad(x.detach())
+    assert (y2 - y.detach()).abs().max().item() > 0
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_inputs(B, S, nh, seed, span2=512):
     from frozenbilm_amd.model.relpos import rel_index_vector
