@@ -54,6 +54,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     sk = max(2, min(16, Kc // 1024))
     o_pk = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), H)
     o_pq = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), 0)
-    L.gemm(G1T, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk)
-    L.gemm(G2T, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk)
+    ws = getattr(eng, "sk_ws", None)
+    L.gemm(G1T, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws)
+    L.gemm(G2T, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws)
     L.cast_bf16(dpos, dpqk)

@@ -9,24 +9,17 @@
 //   dPK = sum_b G1^T.Q ,  dPQ = sum_b G2^T.K     (per head; done by the GEMM kernel on G1^T/G2^T written here)
 //
 // Kernel A  (attn_bwd_ds):  one workgroup per (b, h, 64-key tile), sweeps the query tiles; recomputes P exactly like
-//            the forward (windowed T1/T2 bias GEMMs + LDS gather) but with the KEYS as lane columns, so dV accumulates
-//            in registers; writes dS and dS^T (bf16, zero where masked) -- 2 x SxS bf16 per head is the only extra HBM.
+//            the forward (sub-windowed fp16 T1/T2 bias GEMMs + LDS gather, same rounding) but with the KEYS as lane
+//            columns, so dV accumulates in registers; writes dS and dS^T (bf16, zero where masked) -- 2 x SxS bf16 per
+//            head is the only extra HBM.  Next query tile prefetched into registers while the current one is computed.
 // Kernel BC (attn_bwd_shear<NEG>): one workgroup per (b, h, 32 rows): X_out = dSx.Y + G.Ptab with the scatter
-//            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS atomics into a [32 x 512] fp32 tile; also writes G^T.
-#include "fbl_common.h"
+//            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS atomics (ds_add_f32) into a [32 x W] fp32 tile, W =
+//            the index range the 32 rows can reach (~S+32 <= 512); also writes G^T for the position-table GEMMs.
+#include "attn_common.h"
 #include "../../include/fbl.h"
 
 namespace {
-
-constexpr int LDT = 132;  // fp32 row stride of T1/T2 windows
-constexpr int LDX = 72;   // bf16 row stride of transposed-operand tiles ([64 d][64 + 8])
-
-__device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int chunk) {
-  return *(const bf16x8*)(base + row * 128 + ((chunk ^ (row & 7)) << 4));
-}
-__device__ __forceinline__ void lds_put(char* base, int row, int chunk, bf16x8 v) {
-  *(bf16x8*)(base + row * 128 + ((chunk ^ (row & 7)) << 4)) = v;
-}
+using namespace attn;
 
 // ------------------------------------------------------------------------------------------- D_i = dO_i . O_i
 __global__ void rowdot_kernel(const bf16* dO, const bf16* O, long ld, float* out, int B, int S, int nh) {
@@ -63,19 +56,23 @@ struct BwdAArgs {
   int B, S, Sp, nh, span2;
 };
 
-constexpr int A_QS = 0;                           // [64 i][64] swz
-constexpr int A_DOS = A_QS + 8192;                // [64 i][64] swz
-constexpr int A_DOT = A_DOS + 8192;               // [64 d][72]
-constexpr int A_PK = A_DOT + 64 * LDX * 2;        // [128][64] swz
+constexpr int A_QS = 0;                          // [64 i][64] swz
+constexpr int A_DOS = A_QS + 8192;               // [64 i][64] swz
+constexpr int A_PK = A_DOS + 8192;               // [128][64] swz
 constexpr int A_PQ = A_PK + 16384;
-constexpr int A_T1 = A_PQ + 16384;                // [64 i][LDT] fp32 (shared)
-constexpr int A_T2 = A_T1 + 64 * LDT * 4;         // [4][16][LDT] fp32 (wave private, per key)
-constexpr int A_DST = A_T2 + 64 * LDT * 4;        // [64 i][72] bf16 staging of the dS tile
-constexpr int A_IDX = A_DST + 64 * LDX * 2;       // int16[1024]
-constexpr int A_ROW = A_IDX + 2048;               // float lse[64], D[64], qvalid[64]
+constexpr int A_T1 = A_PQ + 16384;               // [64 i][LT] fp16 (shared)  -- reused as the [64][72] bf16 dS staging tile
+constexpr int A_T2 = A_T1 + 64 * LT * 2;         // [4][16][LT] fp16 (wave private, per key)
+constexpr int A_IDX = A_T2 + 64 * LT * 2;        // int16[1024]
+constexpr int A_ROW = A_IDX + 2048;              // float lse[64], D[64], qvalid[64]
 constexpr int A_TOTAL = A_ROW + 768;
+static_assert(64 * LT * 2 >= 64 * LDV * 2, "dS staging tile must fit in the T1 region");
 
-__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(BwdAArgs a) {
+struct ATileRegs {
+  bf16x8 q[2], d[2], pk[4], pq[4];
+  float lse, D, qv;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,14 +81,15 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(BwdAArgs a) {
   const int S = a.S, Sp = a.Sp;
   const int j = j0 + w * 16 + c;  // this lane's key
   const int jc = min(j, S - 1);
+  const int hi = 2 * S - 2;
 
   int16_t* idx = (int16_t*)(smem + A_IDX);
-  float* T1 = (float*)(smem + A_T1);
-  float* T2w = (float*)(smem + A_T2) + w * 16 * LDT;
+  f16* T1 = (f16*)(smem + A_T1);
+  f16* T2w = (f16*)(smem + A_T2) + w * 16 * LT;
   float* rlse = (float*)(smem + A_ROW);
   float* rD = rlse + 64;
   float* rqv = rD + 64;
-  bf16* dst = (bf16*)(smem + A_DST);
+  bf16* dst = (bf16*)(smem + A_T1);
 
   for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
 
@@ -111,92 +109,127 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(BwdAArgs a) {
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
+  const bf16* dOTh = a.dOT + h * a.t_sh + b * a.t_sb;
   const int nqt = Sp / 64;
   __syncthreads();
 
-  for (int it = 0; it < nqt; ++it) {
+  const int srow = tid >> 3, sch = tid & 7;
+  auto load_tile = [&](int it, ATileRegs& R) {
     const int i0 = it * 64;
-    const int dmin = min(max(i0 - (j0 + 63) + S - 1, 0), 2 * S - 2);
-    const int r_lo = idx[dmin];
-    // ---- stage Q tile, dO tile (row-major, swizzled), dO^T tile, PK/PQ windows, per-query scalars
+    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int id = tid + t * 256;
-      const int row = id >> 3, ch = id & 7;
-      const int i = min(i0 + row, S - 1);
-      lds_put(smem + A_QS, row, ch, *(const bf16x8*)(a.q + ((long)b * S + i) * a.ldq + h * 64 + ch * 8));
-      lds_put(smem + A_DOS, row, ch, *(const bf16x8*)(a.dO + ((long)b * S + i) * a.ldo + h * 64 + ch * 8));
-      *(bf16x8*)(smem + A_DOT + row * (LDX * 2) + ch * 16) =
-          *(const bf16x8*)(a.dOT + h * a.t_sh + b * a.t_sb + row * a.t_sd + i0 + ch * 8);
+      const int i = min(i0 + srow + t * 32, S - 1);
+      R.q[t] = *(const bf16x8*)(a.q + ((long)b * S + i) * a.ldq + h * 64 + sch * 8);
+      R.d[t] = *(const bf16x8*)(a.dO + ((long)b * S + i) * a.ldo + h * 64 + sch * 8);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int id = tid + t * 256;
-      const int row = id >> 3, ch = id & 7;
-      const int r = min(r_lo + row, a.span2 - 1);
-      const long off = (long)r * a.ldp + h * 64 + ch * 8;
-      lds_put(smem + A_PK, row, ch, *(const bf16x8*)(a.pk + off));
-      lds_put(smem + A_PQ, row, ch, *(const bf16x8*)(a.pq + off));
+      const int r = min(r_lo + srow + t * 32, a.span2 - 1);
+      const long off = (long)r * a.ldp + h * 64 + sch * 8;
+      R.pk[t] = *(const bf16x8*)(a.pk + off);
+      R.pq[t] = *(const bf16x8*)(a.pq + off);
     }
+    R.lse = INFINITY; R.D = 0.f; R.qv = 0.f;
     if (tid < 64) {
       const int i = i0 + tid;
-      const bool ok = i < S;
-      const long o = ((long)b * a.nh + h) * S + min(i, S - 1);
-      rlse[tid] = ok ? a.lse[o] : INFINITY;
-      rD[tid] = ok ? a.Dv[o] : 0.f;
-      rqv[tid] = (ok && a.mask[(long)b * S + min(i, S - 1)] != 0) ? 1.f : 0.f;
+      if (i < S) {
+        const long o = ((long)b * a.nh + h) * S + i;
+        R.lse = a.lse[o];
+        R.D = a.Dv[o];
+        R.qv = a.mask[(long)b * S + i] != 0 ? 1.f : 0.f;
+      }
     }
+  };
+  auto store_tile = [&](const ATileRegs& R) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      lds_put(smem + A_QS, srow + t * 32, sch, R.q[t]);
+      lds_put(smem + A_DOS, srow + t * 32, sch, R.d[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      lds_put(smem + A_PK, srow + t * 32, sch, R.pk[t]);
+      lds_put(smem + A_PQ, srow + t * 32, sch, R.pq[t]);
+    }
+    if (tid < 64) {
+      rlse[tid] = R.lse;
+      rD[tid] = R.D;
+      rqv[tid] = R.qv;
+    }
+  };
+
+  ATileRegs R;
+  load_tile(0, R);
+  for (int it = 0; it < nqt; ++it) {
+    const int i0 = it * 64;
+    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    store_tile(R);
     __syncthreads();
+    if (it + 1 < nqt) load_tile(it + 1, R);
+    // sub-window offsets: this wave's 16 keys (T2) and each 16-query tile (T1)
+    const int off2 = idx[clampi(i0 - (j0 + w * 16 + 15) + S - 1, 0, hi)] - r_lo;
+    int off1[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) off1[nt] = idx[clampi(i0 + nt * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
+    const int off1w = idx[clampi(i0 + w * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
 
     // ---- (1) scores: sacc[nt][r] = Q_i . K_j,  i = i0 + nt*16 + g*4 + r, key column c
-    f32x4 sacc[4], dpacc[4];
+    f32x4 sacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_QS, nt * 16 + c, g), kf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_QS, nt * 16 + c, 4 + g), kf[1], acc, 0, 0, 0);
       sacc[nt] = acc;
-      f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, g), vf[0], acc2, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, 4 + g), vf[1], acc2, 0, 0, 0);
-      dpacc[nt] = acc2;
     }
-    // ---- (2) T2 (per key, wave private) and T1 (per query, shared; this wave does queries 16w..16w+15)
-    {
-      const bf16x8 qb0 = lds_frag(smem + A_QS, w * 16 + c, g);
-      const bf16x8 qb1 = lds_frag(smem + A_QS, w * 16 + c, 4 + g);
-#pragma unroll
-      for (int wt = 0; wt < 8; ++wt) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_PQ, wt * 16 + c, g), kf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_PQ, wt * 16 + c, 4 + g), kf[1], acc, 0, 0, 0);
-        *(f32x4*)(T2w + c * LDT + wt * 16 + g * 4) = acc;
-        f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_PK, wt * 16 + c, g), qb0, acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_PK, wt * 16 + c, 4 + g), qb1, acc2, 0, 0, 0);
-        *(f32x4*)(T1 + (w * 16 + c) * LDT + wt * 16 + g * 4) = acc2;
-      }
-    }
+    // ---- (2) T2 for this wave's keys (private), T1 for query tile w (shared)
+    bias_tile(smem + A_PQ, off2, kf[0], kf[1], T2w + c * LT, c, g);
+    bias_tile(smem + A_PK, off1w, lds_frag(smem + A_QS, w * 16 + c, g), lds_frag(smem + A_QS, w * 16 + c, 4 + g),
+              T1 + (w * 16 + c) * LT, c, g);
     __syncthreads();
 
-    // ---- (3) P, dP, dS
-    float p[16], ds[16];
+    // ---- (3) P (same arithmetic as the forward)
+    float p[16];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = nt * 16 + g * 4 + r;
-        const int i = i0 + il;
-        const int di = min(max(i - j + S - 1, 0), 2 * S - 2);
-        const int wi = min(max((int)idx[di] - r_lo, 0), 127);
-        const float s = (sacc[nt][r] + T1[il * LDT + wi] + T2w[c * LDT + wi]) * a.scale;
-        float pv = (kvalid * rqv[il] != 0.f) ? __expf(s - rlse[il]) : 0.f;
+        const int wi = (int)idx[clampi(i0 + il - j + S - 1, 0, hi)] - r_lo;
+        const int w1 = clampi(wi - off1[nt], 0, 79), w2 = clampi(wi - off2, 0, 79);
+        const float s = (sacc[nt][r] + (float)T1[il * LT + w1] + (float)T2w[c * LT + w2]) * a.scale;
+        p[nt * 4 + r] = (kvalid * rqv[il] != 0.f) ? __expf(s - rlse[il]) : 0.f;
+      }
+    }
+    // dO^T fragments of this query tile straight from global (A operand of dV^T += dO^T . P); issued here so their
+    // latency hides under the dP MFMAs
+    bf16x4 dot[4][2][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16* p0 = dOTh + (long)(dt * 16 + c) * a.t_sd + i0 + kk * 32 + g * 4;
+        dot[dt][kk][0] = *(const bf16x4*)p0;
+        dot[dt][kk][1] = *(const bf16x4*)(p0 + 16);
+      }
+    // ---- dP = dO.V^T, dS = P*(dP - D)*scale; packed to bf16 at once (dsb: dS, pfh: dropped-out P for the dV MFMA)
+    bf16x4 dsb[4], pfh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, g), vf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, 4 + g), vf[1], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = nt * 16 + g * 4 + r;
         float keep = 1.f;
         if (a.p_drop > 0.f)
-          keep = fbl_dropout_scale(a.seed, (((uint64_t)b * a.nh + h) * S + (uint64_t)min(i, S - 1)) * S + (uint64_t)jc, thr,
-                                   inv_keep);
-        ds[nt * 4 + r] = pv * (dpacc[nt][r] * keep - rD[il]) * a.scale;
-        p[nt * 4 + r] = pv * keep;
+          keep = fbl_dropout_scale(a.seed, (((uint64_t)b * a.nh + h) * S + (uint64_t)min(i0 + il, S - 1)) * S + (uint64_t)jc,
+                                   thr, inv_keep);
+        const float pv = p[nt * 4 + r];
+        dsb[nt][r] = f2bf(pv * (acc[r] * keep - rD[il]) * a.scale);
+        pfh[nt][r] = f2bf(pv * keep);
       }
     }
     // ---- (4) dV^T += dO^T . drop(P):  k-slot e of step kk <-> query kk*32 + (e>>2)*16 + g*4 + (e&3)
@@ -205,40 +238,36 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(BwdAArgs a) {
       bf16x8 pf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pf[e] = f2bf(p[(2 * kk) * 4 + e]);
-        pf[4 + e] = f2bf(p[(2 * kk + 1) * 4 + e]);
+        pf[e] = pfh[2 * kk][e];
+        pf[4 + e] = pfh[2 * kk + 1][e];
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const char* row = smem + A_DOT + (dt * 16 + c) * (LDX * 2) + (kk * 32 + g * 4) * 2;
-        const bf16x4 v0 = *(const bf16x4*)row;
-        const bf16x4 v1 = *(const bf16x4*)(row + 32);
         bf16x8 af;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          af[e] = v0[e];
-          af[4 + e] = v1[e];
+          af[e] = dot[dt][kk][0][e];
+          af[4 + e] = dot[dt][kk][1][e];
         }
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, dv[dt], 0, 0, 0);
       }
     }
     // ---- (5) dS^T[j][i0 + ..] straight from registers (4 consecutive queries = 8 bytes); dS via an LDS transpose
-    if (j < Sp) {
+    {
       bf16* o = a.dST + sbase + (long)j * Sp + i0 + g * 4;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        *(bf16x4*)(o + nt * 16) = (bf16x4){f2bf(ds[nt * 4]), f2bf(ds[nt * 4 + 1]), f2bf(ds[nt * 4 + 2]), f2bf(ds[nt * 4 + 3])};
+      for (int nt = 0; nt < 4; ++nt) *(bf16x4*)(o + nt * 16) = dsb[nt];
     }
+    __syncthreads();  // every wave is done gathering from T1 -> reuse it as the dS staging tile
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(nt * 16 + g * 4 + r) * LDX + w * 16 + c] = f2bf(ds[nt * 4 + r]);
+      for (int r = 0; r < 4; ++r) dst[(nt * 16 + g * 4 + r) * LDV + w * 16 + c] = dsb[nt][r];
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int id = tid + t * 256;
-      const int row = id >> 3, ch = id & 7;
-      *(bf16x8*)(a.dS + sbase + (long)(i0 + row) * Sp + j0 + ch * 8) = *(const bf16x8*)(dst + row * LDX + ch * 8);
+      const int row = srow + t * 32;
+      *(bf16x8*)(a.dS + sbase + (long)(i0 + row) * Sp + j0 + sch * 8) = *(const bf16x8*)(dst + row * LDV + sch * 8);
     }
     __syncthreads();
   }
@@ -253,19 +282,17 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(BwdAArgs a) {
 
 // ------------------------------------------------------------------------------------------- kernel BC
 struct ShearArgs {
-  const bf16* X;                     // dS (NEG=0) or dS^T (NEG=1): [B,nh,Sp,Sp], rows = output rows
-  const bf16* YT; long y_sh, y_sb, y_sd;   // transposed K (NEG=0) / Q (NEG=1): index h*sh + b*sb + d*sd + s
-  const bf16* PT;                    // transposed position table [nh][64][span2]
+  const bf16* X;                          // dS (NEG=0) or dS^T (NEG=1): [B,nh,Sp,Sp], rows = output rows
+  const bf16* YT; long y_sh, y_sb, y_sd;  // transposed K (NEG=0) / Q (NEG=1): index h*sh + b*sb + d*sd + s
+  const bf16* PT;                         // transposed position table [nh][64][span2]
   const int16_t* relidx;
-  bf16* out; long ldout;             // row-major, head h at col h*64
-  bf16* GT;                          // [nh][span2][B][Sp]
-  int B, S, Sp, nh, span2;
+  bf16* out; long ldout;                  // row-major, head h at col h*64
+  bf16* GT;                               // [nh][span2][B][Sp]
+  int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
 };
-constexpr int LDG = 516;  // fp32 row stride of the G tile (span2 = 512 max)
-constexpr int C_G = 0;                       // [32][LDG] fp32
-constexpr int C_YT = C_G + 32 * LDG * 4;     // [64 d][72] bf16
-constexpr int C_IDX = C_YT + 64 * LDX * 2;   // int16[1024]
-constexpr int C_TOTAL = C_IDX + 2048;
+constexpr int C_YT = 0;                     // [64 d][72] bf16
+constexpr int C_IDX = C_YT + 64 * LDV * 2;  // int16[1024]
+constexpr int C_G = C_IDX + 2048;           // [32][Wg + 4] fp32
 
 template <bool NEG>
 __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
@@ -274,13 +301,17 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int r0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int S = a.S, Sp = a.Sp;
+  const int S = a.S, Sp = a.Sp, hi = 2 * S - 2;
+  const int LDG = a.Wg + 4;
   const int rl = w * 16 + c;  // local row
   const int row = r0 + rl;
   float* G = (float*)(smem + C_G);
   int16_t* idx = (int16_t*)(smem + C_IDX);
   for (int t = tid; t < 32 * LDG; t += 128) G[t] = 0.f;
   for (int t = tid; t < 2 * S - 1; t += 128) idx[t] = a.relidx[t];
+  // smallest reachable index for these 32 rows, aligned down to 8 so the PT fragments stay 16-byte aligned
+  const int dlo = NEG ? -(r0 + 31) : r0 - (S - 1);
+  const int rbase = (int)a.relidx[clampi(dlo + S - 1, 0, hi)] & ~7;
   const long xbase = (((long)b * a.nh + h) * Sp + row) * Sp;
   f32x4 acc[4];
 #pragma unroll
@@ -288,43 +319,60 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   __syncthreads();
 
   const int nct = Sp / 64;
+  bf16x8 xb[2], yst[4];
+  auto load_ct = [&](int ct) {
+    const int c0 = ct * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int id = tid + t * 128;
+      yst[t] = *(const bf16x8*)(a.YT + h * a.y_sh + b * a.y_sb + (id >> 3) * a.y_sd + c0 + (id & 7) * 8);
+    }
+    xb[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
+    xb[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
+  };
+  load_ct(0);
   for (int ct = 0; ct < nct; ++ct) {
     const int c0 = ct * 64;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int id = tid + t * 128;
-      const int d = id >> 3, ch = id & 7;
-      *(bf16x8*)(smem + C_YT + d * (LDX * 2) + ch * 16) =
-          *(const bf16x8*)(a.YT + h * a.y_sh + b * a.y_sb + d * a.y_sd + c0 + ch * 8);
+      *(bf16x8*)(smem + C_YT + (id >> 3) * (LDV * 2) + (id & 7) * 16) = yst[t];
     }
-    bf16x8 xb[2];
-    xb[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
-    xb[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
+    const bf16x8 x0 = xb[0], x1 = xb[1];
     __syncthreads();
+    if (ct + 1 < nct) load_ct(ct + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 xv = kk ? x1 : x0;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 af = *(const bf16x8*)(smem + C_YT + (dt * 16 + c) * (LDX * 2) + (kk * 32 + g * 8) * 2);
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xb[kk], acc[dt], 0, 0, 0);
+        const bf16x8 af = *(const bf16x8*)(smem + C_YT + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 8) * 2);
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xv, acc[dt], 0, 0, 0);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = bf2f(xb[kk][e]);
+        const float x = bf2f(xv[e]);
         if (x != 0.f) {
           const int col = c0 + kk * 32 + g * 8 + e;
           const int dlt = NEG ? (col - row) : (row - col);
-          const int di = min(max(dlt + S - 1, 0), 2 * S - 2);
-          atomicAdd(&G[rl * LDG + idx[di]], x);
+          const int gi = clampi((int)idx[clampi(dlt + S - 1, 0, hi)] - rbase, 0, a.Wg - 1);
+          atomicAdd(&G[rl * LDG + gi], x);
         }
       }
     }
     __syncthreads();
   }
-  // ---- table part: acc[d][row] += sum_r PT[d][r] * G[row][r]
-  const int nks = a.span2 / 32;
-  const bf16* pt = a.PT + (long)h * 64 * a.span2;
-  for (int kk = 0; kk < nks; ++kk) {
+  // ---- table part: acc[d][row] += sum_r PT[d][rbase + r] * G[row][r], PT fragments double-buffered from L2
+  const int nks = a.Wg / 32;
+  const bf16* pt = a.PT + (long)h * 64 * a.span2 + rbase + g * 8;
+  auto load_pt = [&](int kk, bf16x8* dstf) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bool ok = rbase + kk * 32 + g * 8 + 8 <= a.span2;
+      dstf[dt] = ok ? *(const bf16x8*)(pt + (long)(dt * 16 + c) * a.span2 + kk * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  auto table_step = [&](int kk, const bf16x8* af) {
     const float* gp = G + rl * LDG + kk * 32 + g * 8;
     const f32x4 g0 = *(const f32x4*)gp;
     const f32x4 g1 = *(const f32x4*)(gp + 4);
@@ -335,10 +383,15 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
       bfv[4 + e] = f2bf(g1[e]);
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16x8 af = *(const bf16x8*)(pt + (long)(dt * 16 + c) * a.span2 + kk * 32 + g * 8);
-      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[dt], 0, 0, 0);
-    }
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfv, acc[dt], 0, 0, 0);
+  };
+  bf16x8 pa[4], pb[4];
+  load_pt(0, pa);
+  for (int kk = 0; kk < nks; kk += 2) {
+    if (kk + 1 < nks) load_pt(kk + 1, pb);
+    table_step(kk, pa);
+    if (kk + 2 < nks) load_pt(kk + 2, pa);
+    if (kk + 1 < nks) table_step(kk + 1, pb);
   }
   if (row < S) {
     bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
@@ -346,12 +399,15 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
   }
-  // ---- G^T[h][r][b][r0 .. r0+31] (bf16): thread -> (r, 8-row chunk)
+  // ---- G^T[h][r][b][r0 .. r0+31] (bf16), zero outside [rbase, rbase+Wg): thread -> (r, 8-row chunk)
   for (int id = tid; id < a.span2 * 4; id += 128) {
     const int r = id >> 2, ch = id & 3;
-    bf16x8 v;
+    const int gr = r - rbase;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (gr >= 0 && gr < a.Wg) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = f2bf(G[(ch * 8 + e) * LDG + r]);
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(G[(ch * 8 + e) * LDG + gr]);
+    }
     *(bf16x8*)(a.GT + (((long)h * a.span2 + r) * a.B + b) * Sp + r0 + ch * 8) = v;
   }
 }
@@ -398,21 +454,26 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
+  // index range reachable from 32 consecutive rows: <= S + 31 entries (idx has slope <= 1), +7 for the 8-alignment
+  int Wg = S + 31 + 7;
+  if (Wg > span2) Wg = span2;
+  Wg = (Wg + 31) / 32 * 32;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, (bf16*)out, ldout, (bf16*)GT,
-              B, S, Sp, nh, span2};
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL);
-    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL);
+              B, S, Sp, nh, span2, Wg};
+  const int smem_bytes = C_G + 32 * (Wg + 4) * 4;
+  static int attr_bytes = 0;
+  if (smem_bytes > attr_bytes) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e1 != hipSuccess) return (int)e1;
     if (e2 != hipSuccess) return (int)e2;
-    attr_set = true;
+    attr_bytes = smem_bytes;
   }
   dim3 grid(Sp / 32, nh, B);
   if (neg)
-    hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), C_TOTAL, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), C_TOTAL, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -4,20 +4,20 @@
 //   reference: model/deberta.py:717-818 + :820-947 + XSoftmax :100-138   
 //
 // One workgroup (4 waves) = one (batch, head, 64-query tile); it sweeps the keys in tiles of 64 with an online
-// softmax.  For a (query tile, key tile) pair the relative index idx(i-j) only spans <=127 consecutive rows of the
-// position tables (idx is monotone with slope <= 1 in delta), so both bias terms are MFMA GEMMs against a 128-row
-// WINDOW of PK / PQ staged in LDS:   T1 = Q_tile . PKwin^T  [64 x 128],   T2 = K_tile . PQwin^T  [64 x 128]
-// followed by an LDS gather  c2p[i,j] = T1[i][idx(i-j)-lo],  p2c[i,j] = T2[j][idx(i-j)-lo].  Nothing of size SxS or
+// softmax.  For a (query tile, key tile) pair idx(i-j) spans <= 127 consecutive rows of the position tables (idx is
+// monotone with slope <= 1), so both bias terms are MFMA GEMMs against a 128-row WINDOW of PK / PQ staged in LDS,
+//     T1[i][w] = Q_i . PKwin[w]   (per wave: its 16 queries need an 80-row sub-window)
+//     T2[j][w] = K_j . PQwin[w]   (per 16-key tile: 80-row sub-window; wave w computes key tile w, all waves read it)
+// followed by an LDS gather  c2p[i,j] = T1[i][idx(i-j)-..],  p2c[i,j] = T2[j][idx(i-j)-..].  Nothing of size SxS or
 // Sx512 ever reaches HBM.  All MFMAs are "swapped" (keys/positions as A rows, queries as B columns): a lane owns ONE
 // query column, so softmax statistics are in-lane + 2 shuffles, and P feeds the P.V MFMA straight from registers
-// (the k-slot order of that MFMA is permuted identically on the V^T operand).
-#include "fbl_common.h"
+// (the k-slot order of that MFMA is permuted identically on the V^T operand).  The next key tile's global loads are
+// issued into registers before the current tile is computed (HBM/L2 latency hides under the MFMA + LDS work).
+#include "attn_common.h"
 #include "../../include/fbl.h"
 
 namespace {
-
-constexpr int LDT = 132;  // fp32 row stride of T1/T2 (528 B: 16B-aligned rows, spreads banks)
-constexpr int LDV = 72;   // bf16 row stride of the V^T tile (144 B: conflict-free ds_read_b64)
+using namespace attn;
 
 struct AttnArgs {
   const bf16* q; const bf16* k; const bf16* vt; const bf16* pk; const bf16* pq;
@@ -33,22 +33,22 @@ struct AttnArgs {
   int B, S, Sp, nh, span2;
 };
 
-constexpr int SM_KS = 0;                         // [64][64] bf16, 16B chunks XOR-swizzled by row&7
-constexpr int SM_VT = SM_KS + 64 * 128;          // [64 d][72] bf16
-constexpr int SM_PK = SM_VT + 64 * LDV * 2;      // [128][64] bf16 swizzled
-constexpr int SM_PQ = SM_PK + 128 * 128;         // [128][64] bf16 swizzled
-constexpr int SM_T1 = SM_PQ + 128 * 128;         // [4 waves][16][LDT] fp32
-constexpr int SM_T2 = SM_T1 + 4 * 16 * LDT * 4;  // [64][LDT] fp32
-constexpr int SM_IDX = SM_T2 + 64 * LDT * 4;     // int16 [1024]
-constexpr int SM_KM = SM_IDX + 2048;             // float [64] key validity
+constexpr int SM_KS = 0;                        // [64][64] bf16 swizzled
+constexpr int SM_VT = SM_KS + 8192;             // [64 d][72] bf16
+constexpr int SM_PK = SM_VT + 64 * LDV * 2;     // [128][64] bf16 swizzled
+constexpr int SM_PQ = SM_PK + 16384;
+constexpr int SM_T1 = SM_PQ + 16384;            // [4 waves][16][LT] fp16
+constexpr int SM_T2 = SM_T1 + 4 * 16 * LT * 2;  // [64 keys][LT] fp16
+constexpr int SM_IDX = SM_T2 + 64 * LT * 2;     // int16 [1024]
+constexpr int SM_KM = SM_IDX + 2048;            // float [64] key validity
 constexpr int SM_TOTAL = SM_KM + 256;
 
-__device__ __forceinline__ bf16x8 lds_frag(const char* base, int row, int chunk) {
-  // swizzled [rows][8 chunks of 16B] image
-  return *(const bf16x8*)(base + row * 128 + ((chunk ^ (row & 7)) << 4));
-}
+struct TileRegs {  // one key tile in flight: 12 x 16 B per thread
+  bf16x8 k[2], v[2], pk[4], pq[4];
+  float km;
+};
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,12 +60,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
   int16_t* idx = (int16_t*)(smem + SM_IDX);
   float* kms = (float*)(smem + SM_KM);
-  float* T1w = (float*)(smem + SM_T1) + w * 16 * LDT;
-  float* T2 = (float*)(smem + SM_T2);
+  f16* T1w = (f16*)(smem + SM_T1) + w * 16 * LT;
+  f16* T2 = (f16*)(smem + SM_T2);
 
   for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
 
-  // Q fragments (B operand: column = query c, k-slots g*8..g*8+7 of each 32-wide d step)
   bf16x8 qf[2];
   {
     const bf16* qp = a.q + ((long)b * S + ic) * a.ldq + h * 64 + g * 8;
@@ -82,69 +81,78 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const int nkt = (S + 63) / 64;
+  const int hi = 2 * S - 2;
   __syncthreads();  // idx table visible
 
-  for (int jt = 0; jt < nkt; ++jt) {
+  const int srow = tid >> 3, sch = tid & 7;  // staging role of this thread: row (0..31) and 16-byte chunk
+  auto load_tile = [&](int jt, TileRegs& R) {
     const int j0 = jt * 64;
-    const int dmin = min(max(i0 - (j0 + 63) + S - 1, 0), 2 * S - 2);
-    const int r_lo = idx[dmin];
-    // ---- stage K tile, V^T tile, PK/PQ windows, key mask
+    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int id = tid + t * 256;
-      const int row = id >> 3, ch = id & 7;
+      const int row = srow + t * 32;
       const int j = min(j0 + row, S - 1);
-      const bf16x8 kv = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + ch * 8);
-      *(bf16x8*)(smem + SM_KS + row * 128 + ((ch ^ (row & 7)) << 4)) = kv;
-      const bf16x8 vv = *(const bf16x8*)(a.vt + h * a.v_sh + b * a.v_sb + row * a.v_sd + j0 + ch * 8);
-      *(bf16x8*)(smem + SM_VT + row * (LDV * 2) + ch * 16) = vv;
+      R.k[t] = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + sch * 8);
+      R.v[t] = *(const bf16x8*)(a.vt + h * a.v_sh + b * a.v_sb + row * a.v_sd + j0 + sch * 8);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int id = tid + t * 256;
-      const int row = id >> 3, ch = id & 7;
-      const int r = min(r_lo + row, a.span2 - 1);
-      const long off = (long)r * a.ldp + h * 64 + ch * 8;
-      *(bf16x8*)(smem + SM_PK + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const bf16x8*)(a.pk + off);
-      *(bf16x8*)(smem + SM_PQ + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const bf16x8*)(a.pq + off);
+      const int r = min(r_lo + srow + t * 32, a.span2 - 1);
+      const long off = (long)r * a.ldp + h * 64 + sch * 8;
+      R.pk[t] = *(const bf16x8*)(a.pk + off);
+      R.pq[t] = *(const bf16x8*)(a.pq + off);
     }
+    R.km = 0.f;
     if (tid < 64) {
       const int j = j0 + tid;
-      kms[tid] = (j < S && a.mask[(long)b * S + min(j, S - 1)] != 0) ? 1.f : 0.f;
+      R.km = (j < S && a.mask[(long)b * S + min(j, S - 1)] != 0) ? 1.f : 0.f;
     }
+  };
+  auto store_tile = [&](const TileRegs& R) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = srow + t * 32;
+      lds_put(smem + SM_KS, row, sch, R.k[t]);
+      *(bf16x8*)(smem + SM_VT + row * (LDV * 2) + sch * 16) = R.v[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = srow + t * 32;
+      lds_put(smem + SM_PK, row, sch, R.pk[t]);
+      lds_put(smem + SM_PQ, row, sch, R.pq[t]);
+    }
+    if (tid < 64) kms[tid] = R.km;
+  };
+
+  TileRegs R;
+  load_tile(0, R);
+  for (int jt = 0; jt < nkt; ++jt) {
+    const int j0 = jt * 64;
+    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    store_tile(R);
     __syncthreads();
+    if (jt + 1 < nkt) load_tile(jt + 1, R);  // in flight while this tile is computed
+
+    // sub-window offsets: this wave's 16 queries (T1) and each 16-key tile (T2)
+    const int off1 = idx[clampi(i0 + w * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
+    int off2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) off2[nt] = idx[clampi(i0 - (j0 + nt * 16 + 15) + S - 1, 0, hi)] - r_lo;
+    const int off2w = idx[clampi(i0 - (j0 + w * 16 + 15) + S - 1, 0, hi)] - r_lo;
 
     // ---- (1) content scores, transposed: sacc[nt][r] = Q_i . K_j,  j = j0 + nt*16 + g*4 + r
     f32x4 sacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const bf16x8 k0 = lds_frag(smem + SM_KS, nt * 16 + c, g);
-      const bf16x8 k1 = lds_frag(smem + SM_KS, nt * 16 + c, 4 + g);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + SM_KS, nt * 16 + c, g), qf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + SM_KS, nt * 16 + c, 4 + g), qf[1], acc, 0, 0, 0);
       sacc[nt] = acc;
     }
-    // ---- (2) T1[query c][win] (wave private) and (3) T2[key w*16+c][win] (shared)
-    {
-      const bf16x8 kb0 = lds_frag(smem + SM_KS, w * 16 + c, g);
-      const bf16x8 kb1 = lds_frag(smem + SM_KS, w * 16 + c, 4 + g);
-#pragma unroll
-      for (int wt = 0; wt < 8; ++wt) {
-        const bf16x8 p0 = lds_frag(smem + SM_PK, wt * 16 + c, g);
-        const bf16x8 p1 = lds_frag(smem + SM_PK, wt * 16 + c, 4 + g);
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, qf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, qf[1], acc, 0, 0, 0);
-        *(f32x4*)(T1w + c * LDT + wt * 16 + g * 4) = acc;
-        const bf16x8 r0 = lds_frag(smem + SM_PQ, wt * 16 + c, g);
-        const bf16x8 r1 = lds_frag(smem + SM_PQ, wt * 16 + c, 4 + g);
-        f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r0, kb0, acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, kb1, acc2, 0, 0, 0);
-        *(f32x4*)(T2 + (w * 16 + c) * LDT + wt * 16 + g * 4) = acc2;
-      }
-    }
+    // ---- (2) T1 for this wave's queries, (3) T2 for key tile w
+    bias_tile(smem + SM_PK, off1, qf[0], qf[1], T1w + c * LT, c, g);
+    bias_tile(smem + SM_PQ, off2w, lds_frag(smem + SM_KS, w * 16 + c, g), lds_frag(smem + SM_KS, w * 16 + c, 4 + g),
+              T2 + (w * 16 + c) * LT, c, g);
     __syncthreads();
 
     // ---- (4) gather the bias terms, mask, online softmax
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jl = nt * 16 + g * 4 + r;
-        const int di = min(max(i - (j0 + jl) + S - 1, 0), 2 * S - 2);
-        const int wi = min(max((int)idx[di] - r_lo, 0), 127);
-        float s = (sacc[nt][r] + T1w[c * LDT + wi] + T2[jl * LDT + wi]) * a.scale;
+        const int wi = (int)idx[clampi(i - (j0 + jl) + S - 1, 0, hi)] - r_lo;
+        const int w1 = clampi(wi - off1, 0, 79), w2 = clampi(wi - off2[nt], 0, 79);
+        float s = (sacc[nt][r] + (float)T1w[c * LT + w1] + (float)T2[jl * LT + w2]) * a.scale;
         s = (kms[jl] * qvalid != 0.f) ? s : -INFINITY;
         p[nt * 4 + r] = s;
         mx = fmaxf(mx, s);
@@ -234,14 +242,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
                                    int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp,
-                                   const int16_t* relidx,
-                                   const int32_t* mask, float scale, float p_drop, uint64_t seed, void* ctx,
-                                   int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2, void* stream) {
+                                   const int16_t* relidx, const int32_t* mask, float scale, float p_drop, uint64_t seed,
+                                   void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
+                                   void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldp % 8) || (ldo % 4) || (v_sh % 8) || (v_sb % 8) || (v_sd % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, v_sh, v_sb, v_sd, relidx,
-             mask, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, v_sh,
+             v_sb, v_sd, relidx, mask, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL);

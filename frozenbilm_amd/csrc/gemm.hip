@@ -38,6 +38,8 @@ struct GemmArgs {
   long sA, sB, sC, sAux, sBias;  // batch strides in elements
   int splitk;
   int tiles_m, tiles_n;
+  float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
+  int Nw;
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
       for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * g.alpha;
       const bool full = (n4 + 3 < g.N);
       if (SPLITK) {
+        if (g.ws) {  // plain 16-byte stores of the partial tile; folded into out_f32 by splitk_reduce_kernel
+          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
+          continue;
+        }
         if (ks == 0 && bias)
           for (int r = 0; r < 4; ++r)
             if (n4 + r < g.N) v[r] += bias[n4 + r];
@@ -209,18 +215,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   }
 }
 
+// out[b][m][n] += sum_ks ws[b][ks][m][n]   (deterministic split-K fold)
+__global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, int Nw, float* out, long ldc, long sC) {
+  const int b = blockIdx.y;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index inside [M][Nw/4]
+  const int nq = Nw >> 2;
+  if (q >= (long)M * nq) return;
+  const int m = (int)(q / nq), n4 = (int)(q % nq) * 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* p = ws + ((long)b * splitk * M + m) * Nw + n4;
+  for (int k = 0; k < splitk; ++k) acc += *(const f32x4*)(p + (long)k * M * Nw);
+  float* o = out + b * sC + (long)m * ldc + n4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (n4 + r < N) o[r] += acc[r];
+}
+
 }  // namespace
 
 extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                                 const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
                                 const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
                                 int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
-                                int64_t strideAux, int64_t strideBias, int splitk, void* stream) {
+                                int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
+                                int64_t splitk_ws_floats, void* stream) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
   if (splitk < 1) splitk = 1;
-  if (splitk > 1 && (!out_f32 || out_bf16 || out_pre_bf16 || act != FBL_ACT_NONE || aux_kind != FBL_AUX_NONE))
+  const bool accumulate = splitk > 1;  // callers ask for splitk >= 2 when they want "out += A.B^T"
+  if (splitk > 1) {  // every split must own at least one K tile
+    const int nk = K / BK;
+    const int per = (nk + splitk - 1) / splitk;
+    splitk = (nk + per - 1) / per;
+  }
+  const int Nw = (N + 3) & ~3;
+  if (accumulate && splitk_ws && (int64_t)batch * splitk * M * Nw > splitk_ws_floats) splitk_ws = nullptr;  // too small
+  if (accumulate && bias && splitk_ws) return FBL_ERR_ARG;
+  if (accumulate && (!out_f32 || out_bf16 || out_pre_bf16 || act != FBL_ACT_NONE || aux_kind != FBL_AUX_NONE))
     return FBL_ERR_ARG;  // split-K only accumulates (atomicAdd) into a pre-initialised fp32 output
   if (!out_f32 && !out_bf16) return FBL_ERR_ARG;
   GemmArgs g;
@@ -231,6 +263,8 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out_pre = (bf16*)out_pre_bf16; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sAux = strideAux; g.sBias = strideBias;
   g.splitk = splitk;
+  g.ws = accumulate ? splitk_ws : nullptr;
+  g.Nw = Nw;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
@@ -246,7 +280,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, dim3(256), smem_bytes, (hipStream_t)stream, g);                              \
   } while (0)
-  if (splitk > 1) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
+  if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
   else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_RELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_RELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, false);
@@ -256,6 +290,12 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_POS_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_POS_BF16, false);
   else return FBL_ERR_ARG;
 #undef FBL_GEMM_LAUNCH
+  FBL_CHECK_LAUNCH();
+  if (accumulate && g.ws) {
+    const long nq = (long)M * (Nw >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)g.ws, splitk, M, N, Nw, out_f32, (long)ldc, (long)strideC);
+  }
   FBL_CHECK_LAUNCH();
   return 0;
 }

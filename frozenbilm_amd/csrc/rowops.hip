@@ -242,13 +242,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     a.ws[(long)blockIdx.x * 2 * H + i] = s;
   }
 }
-__global__ void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * H) return;
+// fold [nblk][ncols] partial sums: a block owns 16 columns, its 16 row-groups stride over the partial rows
+__device__ __forceinline__ float fold16(const float* ws, int nblk, int ncols, int col) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(long)b * 2 * H + i];
-  if (i < H) dgamma[i] += s;
-  else dbeta[i - H] += s;
+  if (col < ncols)
+    for (int b = ty; b < nblk; b += 16) s += ws[(long)b * ncols + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][tx];
+  }
+  return s;
+}
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = fold16(ws, nblk, 2 * H, i);
+  if ((threadIdx.x >> 4) == 0 && i < 2 * H) {
+    if (i < H) dgamma[i] += s;
+    else dbeta[i - H] += s;
+  }
 }
 
 __global__ void embed_gather_kernel(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
@@ -340,12 +355,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* in_, long ld_in
       s += IN_BF16 ? bf2f(((const bf16*)in_)[(long)r * ld_in + c]) : ((const float*)in_)[(long)r * ld_in + c];
   if (c < cols) ws[(long)blockIdx.x * cols + c] = s;
 }
-__global__ void colsum_fold_kernel(const float* ws, int nblk, int cols, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(long)b * cols + c];
-  out[c] += s;
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* ws, int nblk, int cols, float* out) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = fold16(ws, nblk, cols, c);
+  if ((threadIdx.x >> 4) == 0 && c < cols) out[c] += s;
 }
 
 // Vt[b,h,d,s] = V[b*S+s, h*64+d]; one block per (s-tile of 64, h, b)
@@ -546,7 +559,7 @@ extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float
   FBL_EPL_DISPATCH(H, ln_bwd_kernel, grid, a, (hipStream_t)stream);
   FBL_CHECK_LAUNCH();
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
                        dgamma, dbeta);
     FBL_CHECK_LAUNCH();
   }
@@ -612,7 +625,7 @@ extern "C" int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int row
   else
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols, ws);
   FBL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nblk, cols,
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, cols,
                      out);
   FBL_CHECK_LAUNCH();
   return 0;

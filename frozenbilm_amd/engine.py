@@ -76,6 +76,7 @@ class Engine:
         self.skip_dead_layer = True
         self._ln_ws = L.ln_bwd_ws(self.H, dev)
         self._cs_ws = L.colsum_ws(max(self.H, self.I), dev)
+        self.sk_ws = torch.empty(16 << 20, dtype=F32, device=dev)  # 64 MiB split-K partials
 
     # ------------------------------------------------------------------ parameter plumbing
     def _build_flat(self):
@@ -507,8 +508,8 @@ class Engine:
         L.transpose_to_bf16(xin_b, xT)
         sk = max(2, min(16, Np // 512))  # >= 2: the split-K path ACCUMULATES (atomicAdd) into the grad buffer
         nm = ent["name"]
-        L.gemm(dyT, zT, out_f32=self.G[nm + ".up.weight"], N=A, splitk=sk)      # dWu[H,A] += dy^T z
-        L.gemm(dzT, xT, out_f32=self.G[nm + ".down.weight"], M=A, splitk=sk)    # dWd[A,H] += dz^T x
+        L.gemm(dyT, zT, out_f32=self.G[nm + ".up.weight"], N=A, splitk=sk, ws=self.sk_ws)      # dWu[H,A] += dy^T z
+        L.gemm(dzT, xT, out_f32=self.G[nm + ".down.weight"], M=A, splitk=sk, ws=self.sk_ws)    # dWd[A,H] += dz^T x
         L.colsum(dyb, self.G[nm + ".up.bias"], self._cs_ws)
         L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)
         return dx

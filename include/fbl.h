@@ -34,14 +34,16 @@ int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
  * epi: v = alpha*acc + bias[n]; v *= rowscale[m]; pre = v; v = act(v); v = aux-op(v); -> out_f32 / out_bf16 (/ out_pre).
- * batch > 1: strided batch (strides in elements).  splitk > 1: atomicAdd of partial products into out_f32.
+ * batch > 1: strided batch (strides in elements).  splitk > 1: ACCUMULATE mode, out_f32 += A.B^T with the K range
+ * split over `splitk` workgroup sets; partial tiles go to `splitk_ws` (>= batch*splitk*M*roundup(N,4) floats) and are
+ * folded deterministically by a second tiny kernel; with splitk_ws == NULL (or too small) they are atomicAdd-ed.
  * ref: every nn.Linear on the path -- model/deberta.py:255,311,329,757-765,847-853,994,1545,1550;
  *      model/adapter.py:38,42; conv1d deberta.py:397 (as K=3H GEMM); and their autograd dX/dW. */
 int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
                      const float* rowscale, float alpha, int act, int aux_kind, const void* aux, int64_t ld_aux,
                      float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
-                     void* stream);
+                     float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 
 /* t0[b, s, :] = s < T ? vproj[b*T + s, :] : E[ids[b, s-T], :]     (fp32).  vproj may be NULL (T = 0).
  * ref: model/deberta.py:1012-1016 (word_embeddings + cat with linear_video output). */

@@ -105,13 +105,21 @@ def test_gemm_splitk_accumulates_and_batched(L):
     A, B = bf(rnd(M, K, seed=1)).to(BF16), bf(rnd(N, K, seed=2, scale=0.1)).to(BF16)
     out = torch.ones(M, N, dtype=F32, device=DEV)
     L.gemm(A, B, out_f32=out, splitk=8)
-    close(out, 1.0 + A.float() @ B.float().t(), 1e-4, 2e-3, "splitk")
+    close(out, 1.0 + A.float() @ B.float().t(), 1e-4, 2e-3, "splitk atomic")
+    ws = torch.empty(1 << 20, dtype=F32, device=DEV)
+    out = torch.ones(M, N + 2, dtype=F32, device=DEV)
+    L.gemm(A, B, out_f32=out, splitk=8, ws=ws, N=N - 2)  # N not a multiple of 4, workspace path (deterministic fold)
+    close(out[:, :N - 2], 1.0 + (A.float() @ B.float().t())[:, :N - 2], 1e-4, 2e-3, "splitk ws")
+    assert (out[:, N - 2:] == 1.0).all()
+    out2 = torch.ones(M, N + 2, dtype=F32, device=DEV)
+    L.gemm(A, B, out_f32=out2, splitk=8, ws=ws, N=N - 2)
+    assert torch.equal(out, out2), "workspace split-K must be bit-reproducible"
     # strided batch with per-batch column offset in the output (position-table gradient layout)
     nb, Mb, Nb, Kb = 3, 100, 64, 128
     A3, B3 = bf(rnd(nb, Mb, Kb, seed=4)).to(BF16), bf(rnd(nb, Nb, Kb, seed=5)).to(BF16)
     out = torch.zeros(Mb, nb * Nb + 64, dtype=F32, device=DEV)
     o3 = torch.as_strided(out, (nb, Mb, Nb), (Nb, out.shape[1], 1), 64)
-    L.gemm(A3, B3, out_f32=o3, splitk=2)
+    L.gemm(A3, B3, out_f32=o3, splitk=2, ws=torch.empty(1 << 18, dtype=F32, device=DEV))
     ref = torch.einsum("bmk,bnk->bmn", A3.float(), B3.float())
     for b in range(nb):
         close(out[:, 64 + b * Nb: 64 + (b + 1) * Nb], ref[b], 1e-4, 1e-3, f"batched {b}")
@@ -376,7 +384,7 @@ def test_adapter_module_gate_matched(L, H, ds, N):
     zz = zr + (z - zr).detach()
     yr = xr + F.linear(zz, wu, bu)
     yr.backward(gy)
-    close(y, yr, 1e-3, 1e-3, "adapter y")
+    close(y, yr, 1e-3, 6e-3, "adapter y")  # z is rounded to bf16: 1-ulp differences at rounding boundaries
     sc = lambda t: t.abs().max().item()
     close(x.grad, xr.grad, 2e-2, 1e-2 * sc(xr.grad), "dx")
     close(ad.up.weight.grad, wu.grad, 2e-2, 1e-2 * sc(wu.grad), "dWu")
