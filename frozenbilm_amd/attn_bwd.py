@@ -24,6 +24,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
     pq, pk = sv.pqk[:, :H], sv.pqk[:, H:]
     relidx = eng.relidx(S)
+    klen = getattr(run, "klen", None)
     scale = 1.0 / math.sqrt(64 * 3)
 
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
@@ -37,7 +38,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     L.disent_attn_bwd_ds(q, k, v, dctx, dOT, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
-                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, t_head_major=True)
+                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, t_head_major=True, klen=klen)
     del dOT
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
@@ -45,8 +46,8 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
     G1T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
     G2T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
-    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2)
-    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2)
+    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen)
+    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen)
     del dS, dST
     # position tables: fp32 [span2, 2H] laid out [dPQ | dPK]; head h writes columns h*64 .. h*64+63
     dpos = torch.zeros(span2, 2 * H, dtype=F32, device=dev)

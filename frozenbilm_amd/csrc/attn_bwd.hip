@@ -48,7 +48,7 @@ struct BwdAArgs {
   const bf16* dO; long ldo;                               // row-major [B*S, ldo]
   const bf16* dOT; long t_sh, t_sb, t_sd;                 // transposed dO: index h*sh + b*sb + d*sd + s
   const bf16* pk; const bf16* pq; long ldp;
-  const int16_t* relidx; const int32_t* mask;
+  const int16_t* relidx; const int32_t* mask; const int32_t* klen;
   const float* lse; const float* Dv;                      // [B,nh,S]
   float scale, p_drop; uint64_t seed;
   bf16* dV; long lddv;                                    // row-major out, head h at col h*64
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   float* rlse = (float*)(smem + A_ROW);
   float* rD = rlse + 64;
   float* rqv = rD + 64;
-  bf16* dst = (bf16*)(smem + A_T1);
+  bf16* dst = (bf16*)(smem + A_T1);   // dS tile [query][key] after the gather
+  bf16* dstT = (bf16*)(smem + A_T2);  // dS^T tile [key][query]
 
   for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
 
@@ -110,25 +111,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
   const bf16* dOTh = a.dOT + h * a.t_sh + b * a.t_sb;
-  const int nqt = Sp / 64;
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;  // tiles beyond the last valid position: dS = 0 (never read), dV = 0
   __syncthreads();
 
   const int srow = tid >> 3, sch = tid & 7;
-  auto load_tile = [&](int it, ATileRegs& R) {
+  auto load_qd = [&](int it, ATileRegs& R) {
     const int i0 = it * 64;
-    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int i = min(i0 + srow + t * 32, S - 1);
       R.q[t] = *(const bf16x8*)(a.q + ((long)b * S + i) * a.ldq + h * 64 + sch * 8);
       R.d[t] = *(const bf16x8*)(a.dO + ((long)b * S + i) * a.ldo + h * 64 + sch * 8);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = min(r_lo + srow + t * 32, a.span2 - 1);
-      const long off = (long)r * a.ldp + h * 64 + sch * 8;
-      R.pk[t] = *(const bf16x8*)(a.pk + off);
-      R.pq[t] = *(const bf16x8*)(a.pq + off);
     }
     R.lse = INFINITY; R.D = 0.f; R.qv = 0.f;
     if (tid < 64) {
@@ -139,6 +133,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
         R.D = a.Dv[o];
         R.qv = a.mask[(long)b * S + i] != 0 ? 1.f : 0.f;
       }
+    }
+  };
+  auto load_win = [&](int it, ATileRegs& R) {  // issued late in the iteration: keeps 32 VGPRs free during the gather
+    const int i0 = it * 64;
+    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = min(r_lo + srow + t * 32, a.span2 - 1);
+      const long off = (long)r * a.ldp + h * 64 + sch * 8;
+      R.pk[t] = *(const bf16x8*)(a.pk + off);
+      R.pq[t] = *(const bf16x8*)(a.pq + off);
     }
   };
   auto store_tile = [&](const ATileRegs& R) {
@@ -160,13 +165,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   };
 
   ATileRegs R;
-  load_tile(0, R);
+  if (nqt > 0) {
+    load_qd(0, R);
+    load_win(0, R);
+  }
   for (int it = 0; it < nqt; ++it) {
     const int i0 = it * 64;
     const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
     store_tile(R);
     __syncthreads();
-    if (it + 1 < nqt) load_tile(it + 1, R);
+    if (it + 1 < nqt) load_qd(it + 1, R);
+    // dO^T tile of THIS query tile (A operand of dV^T += dO^T . P): global -> registers now, -> LDS (over the dead PK
+    // window) after the bias GEMMs; its latency hides under the score / bias MFMAs
+    bf16x8 dts[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dts[t] = *(const bf16x8*)(dOTh + (long)(srow + t * 32) * a.t_sd + i0 + sch * 8);
     // sub-window offsets: this wave's 16 keys (T2) and each 16-query tile (T1)
     const int off2 = idx[clampi(i0 - (j0 + w * 16 + 15) + S - 1, 0, hi)] - r_lo;
     int off1[4];
@@ -202,17 +215,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
         p[nt * 4 + r] = (kvalid * rqv[il] != 0.f) ? __expf(s - rlse[il]) : 0.f;
       }
     }
-    // dO^T fragments of this query tile straight from global (A operand of dV^T += dO^T . P); issued here so their
-    // latency hides under the dP MFMAs
-    bf16x4 dot[4][2][2];
+    if (it + 1 < nqt) load_win(it + 1, R);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16* p0 = dOTh + (long)(dt * 16 + c) * a.t_sd + i0 + kk * 32 + g * 4;
-        dot[dt][kk][0] = *(const bf16x4*)p0;
-        dot[dt][kk][1] = *(const bf16x4*)(p0 + 16);
-      }
+    for (int t = 0; t < 2; ++t) *(bf16x8*)(smem + A_PK + (srow + t * 32) * (LDV * 2) + sch * 16) = dts[t];  // PK window is dead
     // ---- dP = dO.V^T, dS = P*(dP - D)*scale; packed to bf16 at once (dsb: dS, pfh: dropped-out P for the dV MFMA)
     bf16x4 dsb[4], pfh[4];
 #pragma unroll
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
         pfh[nt][r] = f2bf(pv * keep);
       }
     }
+    __syncthreads();  // dO^T tile visible; every wave is done gathering from T1 / T2 (reused below as dS staging)
     // ---- (4) dV^T += dO^T . drop(P):  k-slot e of step kk <-> query kk*32 + (e>>2)*16 + g*4 + (e&3)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -243,31 +249,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
+        const char* drow = smem + A_PK + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 4) * 2;
+        const bf16x4 v0 = *(const bf16x4*)drow;
+        const bf16x4 v1 = *(const bf16x4*)(drow + 32);
         bf16x8 af;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          af[e] = dot[dt][kk][0][e];
-          af[4 + e] = dot[dt][kk][1][e];
+          af[e] = v0[e];
+          af[4 + e] = v1[e];
         }
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, dv[dt], 0, 0, 0);
       }
     }
-    // ---- (5) dS^T[j][i0 + ..] straight from registers (4 consecutive queries = 8 bytes); dS via an LDS transpose
-    {
-      bf16* o = a.dST + sbase + (long)j * Sp + i0 + g * 4;
+    // ---- (5) dS and dS^T leave through LDS transposes (T1 / T2 regions): 16-byte rows
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *(bf16x4*)(o + nt * 16) = dsb[nt];
+    for (int nt = 0; nt < 4; ++nt) {
+      *(bf16x4*)(dstT + (w * 16 + c) * LDV + nt * 16 + g * 4) = dsb[nt];  // [key][query]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(nt * 16 + g * 4 + r) * LDV + w * 16 + c] = dsb[nt][r];  // [query][key]
     }
-    __syncthreads();  // every wave is done gathering from T1 -> reuse it as the dS staging tile
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(nt * 16 + g * 4 + r) * LDV + w * 16 + c] = dsb[nt][r];
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = srow + t * 32;
       *(bf16x8*)(a.dS + sbase + (long)(i0 + row) * Sp + j0 + sch * 8) = *(const bf16x8*)(dst + row * LDV + sch * 8);
+      *(bf16x8*)(a.dST + sbase + (long)(j0 + row) * Sp + i0 + sch * 8) = *(const bf16x8*)(dstT + row * LDV + sch * 8);
     }
     __syncthreads();
   }
@@ -286,6 +292,7 @@ struct ShearArgs {
   const bf16* YT; long y_sh, y_sb, y_sd;  // transposed K (NEG=0) / Q (NEG=1): index h*sh + b*sb + d*sd + s
   const bf16* PT;                         // transposed position table [nh][64][span2]
   const int16_t* relidx;
+  const int32_t* klen;
   bf16* out; long ldout;                  // row-major, head h at col h*64
   bf16* GT;                               // [nh][span2][B][Sp]
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
@@ -318,7 +325,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int nct = Sp / 64;
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nct = (r0 < kl) ? (kl + 63) / 64 : 0;  // dS is only defined (and non-zero) inside [kl x kl]
   bf16x8 xb[2], yst[4];
   auto load_ct = [&](int ct) {
     const int c0 = ct * 64;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     xb[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
     xb[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
   };
-  load_ct(0);
+  if (nct > 0) load_ct(0);
   for (int ct = 0; ct < nct; ++ct) {
     const int c0 = ct * 64;
 #pragma unroll
@@ -349,15 +357,17 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
         const bf16x8 af = *(const bf16x8*)(smem + C_YT + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 8) * 2);
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xv, acc[dt], 0, 0, 0);
       }
+      int gi[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        const int col = c0 + kk * 32 + g * 8 + e;
+        const int dlt = NEG ? (col - row) : (row - col);
+        gi[e] = clampi((int)idx[clampi(dlt + S - 1, 0, hi)] - rbase, 0, a.Wg - 1);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {  // ~2/3 of dS is exactly 0 (padding / masks) and would pile up on a few clamped slots
         const float x = bf2f(xv[e]);
-        if (x != 0.f) {
-          const int col = c0 + kk * 32 + g * 8 + e;
-          const int dlt = NEG ? (col - row) : (row - col);
-          const int gi = clampi((int)idx[clampi(dlt + S - 1, 0, hi)] - rbase, 0, a.Wg - 1);
-          atomicAdd(&G[rl * LDG + gi], x);
-        }
+        if (x != 0.f) atomicAdd(&G[rl * LDG + gi[e]], x);
       }
     }
     __syncthreads();
@@ -386,8 +396,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfv, acc[dt], 0, 0, 0);
   };
   bf16x8 pa[4], pb[4];
-  load_pt(0, pa);
-  for (int kk = 0; kk < nks; kk += 2) {
+  if (nct > 0) load_pt(0, pa);
+  for (int kk = 0; kk < (nct > 0 ? nks : 0); kk += 2) {
     if (kk + 1 < nks) load_pt(kk + 1, pb);
     table_step(kk, pa);
     if (kk + 2 < nks) load_pt(kk + 2, pa);
@@ -428,14 +438,14 @@ extern "C" int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float*
 extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO,
                                       int64_t ldo, const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd,
                                       const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
-                                      const int32_t* mask, const float* lse, const float* Dv, float scale, float p_drop,
+                                      const int32_t* mask, const int32_t* klen, const float* lse, const float* Dv, float scale, float p_drop,
                                       uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
                                       int nh, int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4) || (t_sd % 8) || (t_sb % 8) || (t_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
   BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)dOT, t_sh, t_sb,
-             t_sd, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
+             t_sd, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
              (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2};
   static bool attr_set = false;
   if (!attr_set) {
@@ -449,8 +459,8 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
 }
 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
-                                         int64_t y_sd, const void* PT, const int16_t* relidx, void* out, int64_t ldout,
-                                         void* GT, int B, int S, int Sp, int nh, int span2, void* stream) {
+                                         int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen, void* out,
+                                         int64_t ldout, void* GT, int B, int S, int Sp, int nh, int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
@@ -458,7 +468,7 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   int Wg = S + 31 + 7;
   if (Wg > span2) Wg = span2;
   Wg = (Wg + 31) / 32 * 32;
-  ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, (bf16*)out, ldout, (bf16*)GT,
+  ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, (bf16*)out, ldout, (bf16*)GT,
               B, S, Sp, nh, span2, Wg};
   const int smem_bytes = C_G + 32 * (Wg + 4) * 4;
   static int attr_bytes = 0;

@@ -25,6 +25,7 @@ struct AttnArgs {
   long v_sh, v_sb, v_sd;
   const int16_t* relidx;
   const int32_t* mask;
+  const int32_t* klen;  // [B] last valid position + 1 (tiles beyond it are exactly zero and skipped) or null
   float scale, p_drop;
   uint64_t seed;
   bf16* ctx;
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const int nkt = (S + 63) / 64;
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nkt = (i0 < kl) ? (kl + 63) / 64 : 0;  // masked key tiles contribute exactly 0; a fully masked query tile outputs 0
   const int hi = 2 * S - 2;
   __syncthreads();  // idx table visible
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   };
 
   TileRegs R;
-  load_tile(0, R);
+  if (nkt > 0) load_tile(0, R);
   for (int jt = 0; jt < nkt; ++jt) {
     const int j0 = jt * 64;
     const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
@@ -242,14 +244,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
                                    int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp,
-                                   const int16_t* relidx, const int32_t* mask, float scale, float p_drop, uint64_t seed,
+                                   const int16_t* relidx, const int32_t* mask, const int32_t* klen, float scale,
+                                   float p_drop, uint64_t seed,
                                    void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
                                    void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldp % 8) || (ldo % 4) || (v_sh % 8) || (v_sb % 8) || (v_sd % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
   AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, v_sh,
-             v_sb, v_sd, relidx, mask, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
+             v_sb, v_sd, relidx, mask, klen, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL);

@@ -337,7 +337,7 @@ class Engine:
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
         L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
-                          seed=sv.seed_att)
+                          seed=sv.seed_att, klen=run.klen)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
         o32 = torch.empty(N, H, dtype=F32, device=dev)
         ob = torch.empty(N, H, dtype=BF16, device=dev)
@@ -373,6 +373,8 @@ class Engine:
         B, S, T, Lt = run.B, run.S, run.T, run.Lt
         N = B * S
         run.mask_i32 = run.mask
+        pos1 = torch.arange(1, S + 1, device=dev, dtype=torch.int32)
+        run.klen = (run.mask.view(B, S) * pos1).amax(1).to(torch.int32).contiguous()  # last valid position + 1
         mask_f = run.mask.to(F32)
         run.mask_f = mask_f
         # ---- embeddings (model/deberta.py:997-1058): cat(linear_video(video), E[ids]) -> LN -> *mask -> dropout

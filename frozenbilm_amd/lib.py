@@ -38,12 +38,13 @@ SIGNATURES = {
     "fbl_colsum_ws_floats": (_l, [_i]),
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
-    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _f, _f, _u64, _vp, _l, _vp,
-                                 _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
+                                 _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f,
-                                    _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
+                                    _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i,
+                                       _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
@@ -264,7 +265,7 @@ def head_transpose(v, vt, B, S, Sp, nh, head_major=False):
 
 
 def disent_attn_fwd(q, k, vt, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0,
-                    vt_head_major=False):
+                    vt_head_major=False, klen=None):
     for t, n in ((q, "q"), (k, "k"), (pk, "pk"), (pq, "pq"), (ctx, "ctx"), (vt, "vt")):
         _req(t, torch.bfloat16, n)
     _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
@@ -273,8 +274,8 @@ def disent_attn_fwd(q, k, vt, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, n
     assert _rows2d(pq, "pq") == ldp
     sh, sb, sd = head_strides(B, Sp, nh, vt_head_major)
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(vt), sh, sb, sd, _p(pk), _p(pq), ldp, _p(relidx),
-                                    _p(mask), float(scale), float(p_drop), int(seed), _p(ctx), ldo, _p(lse), B, S, Sp,
-                                    nh, span2, _stream()), "fbl_disent_attn_fwd")
+                                    _p(mask), _p(klen), float(scale), float(p_drop), int(seed), _p(ctx), ldo, _p(lse), B,
+                                    S, Sp, nh, span2, _stream()), "fbl_disent_attn_fwd")
 
 
 def attn_rowdot(dO, O, out, B, S, nh):
@@ -284,22 +285,22 @@ def attn_rowdot(dO, O, out, B, S, nh):
 
 
 def disent_attn_bwd_ds(q, k, v, dO, dOT, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
-                       p_drop=0.0, seed=0, t_head_major=True):
+                       p_drop=0.0, seed=0, t_head_major=True, klen=None):
     ldq = _rows2d(q, "q")
     assert _rows2d(k, "k") == ldq and _rows2d(v, "v") == ldq
     ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
     assert _rows2d(pq, "pq") == ldp
     sh, sb, sd = head_strides(B, Sp, nh, t_head_major)
     _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(dOT), sh, sb, sd, _p(pk), _p(pq), ldp,
-                                       _p(relidx), _p(mask), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
+                                       _p(relidx), _p(mask), _p(klen), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
                                        _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, _stream()),
          "fbl_disent_attn_bwd_ds")
 
 
-def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True):
+def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
-    _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(out), ldout,
+    _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(out), ldout,
                                           _p(GT), B, S, Sp, nh, span2, _stream()), "fbl_disent_attn_bwd_shear")
 
 

@@ -113,18 +113,20 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
  *   rows -> 0), attention-prob dropout, ctx = P.V.   head_dim = 64, S <= 512.
  *   q/k: bf16 rows b*S+s, head h at column h*64 (strides ldq/ldk); vt from fbl_head_transpose (strides v_*);
  *   pk/pq bf16 [2*span, ldp]; relidx int16 [2S-1]: relidx[d+S-1] = clamp(bucket(d)+span, 0, 2span-1);
- *   mask int32 [B,S]; out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
+ *   mask int32 [B,S]; klen int32 [B] (optional): last valid position + 1 -- tiles beyond it are exactly zero and are
+ *   skipped; out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
 int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
                         int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
-                        const int32_t* mask, float scale, float p_drop, uint64_t seed, void* ctx, int64_t ldo,
-                        float* lse, int B, int S, int Sp, int nh, int span2, void* stream);
+                        const int32_t* mask, const int32_t* klen, float scale, float p_drop, uint64_t seed, void* ctx,
+                        int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2, void* stream);
 
 /* Backward of fbl_disent_attn_fwd, three launches (ref: autograd of model/deberta.py:717-947, XSoftmax.backward
  * :134-138, XDropout.backward :185-190):
  *  fbl_attn_rowdot:            Dv[b,h,i] = dO_i . O_i  (per head).
  *  fbl_disent_attn_bwd_ds:     recomputes P; writes dV (bf16, into a row-major buffer), dS and dS^T (bf16 [B,nh,Sp,Sp],
- *                              dS = P*(dP - Dv)*scale, exactly 0 where masked / padded).
+ *                              dS = P*(dP - Dv)*scale, exactly 0 where masked / padded; with klen only the
+ *                              [klen x klen] corner (rounded up to 64) is written and read).
  *  fbl_disent_attn_bwd_shear:  neg=0: out = dQ = dS.K + G1.PK,  G1[i,r] = sum_{j: idx(i-j)=r} dS[i,j]
  *                              neg=1: out = dK = dS^T.Q + G2.PQ, G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]
  *                              X = dS / dS^T; YT = transposed K / Q (fbl_head_transpose strides); PT = transposed
@@ -133,12 +135,13 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
-                           int64_t ldp, const int16_t* relidx, const int32_t* mask, const float* lse, const float* Dv,
+                           int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen, const float* lse,
+                           const float* Dv,
                            float scale, float p_drop, uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B,
                            int S, int Sp, int nh, int span2, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
-                              const void* PT, const int16_t* relidx, void* out, int64_t ldout, void* GT, int B, int S,
-                              int Sp, int nh, int span2, void* stream);
+                              const void* PT, const int16_t* relidx, const int32_t* klen, void* out, int64_t ldout,
+                              void* GT, int B, int S, int Sp, int nh, int span2, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */

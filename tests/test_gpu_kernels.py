@@ -412,7 +412,12 @@ def _attn_inputs(B, S, nh, seed, span2=512):
     return qkv, pqk, mask, relidx, H
 
 
-def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0):
+def _klen(mask):
+    S = mask.shape[1]
+    return (mask * torch.arange(1, S + 1, device=mask.device, dtype=torch.int32)).amax(1).to(torch.int32).contiguous()
+
+
+def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None):
     H = nh * 64
     Sp = (S + 63) // 64 * 64
     vt = torch.empty(B, nh, 64, Sp, dtype=BF16, device=DEV)
@@ -420,7 +425,7 @@ def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0):
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.empty(B, nh, S, device=DEV)
     L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx,
-                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed)
+                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen)
     return ctx, lse
 
 
@@ -439,6 +444,12 @@ def test_attention_fwd(L, B, S, nh):
     close(lse[valid], rlse[valid], 1e-3, 1e-3, "lse")
     assert torch.isinf(lse[~valid]).all()
     assert (got[~valid[:, :, :, None].expand_as(got)] == 0).all()  # masked query rows are exactly zero
+    # skipping the tiles beyond the last valid position (klen) is exact
+    mask2 = mask.clone()
+    mask2[0, S // 3:] = 0
+    c_full, l_full = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh)
+    c_skip, l_skip = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh, klen=_klen(mask2))
+    assert torch.equal(c_full, c_skip) and torch.equal(l_full, l_skip)
 
 
 def test_attention_fwd_dropout_rate(L):
@@ -479,6 +490,7 @@ def test_attention_bwd(L, B, S, nh):
     eng.H, eng.nh, eng.span2, eng.dev = H, nh, pqk.shape[0], torch.device(DEV)
     eng.relidx = lambda S_: relidx
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
+    run.klen = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 0
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
     dpqk = torch.zeros(pqk.shape[0], 2 * H, dtype=BF16, device=DEV)
