@@ -19,6 +19,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 constexpr int NXCD = 8;
+constexpr int SMEM_BYTES = 4 * 64 * 68 * 4;  // max(2 stages x 32 KiB, 4 waves x 64x68 fp32 epilogue tiles) = 69632
 
 struct GemmArgs {
   const bf16* A;
@@ -146,56 +147,76 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns C[m][n4..n4+3],  m = m0+wm*64+mi*16+(lane&15),  n4 = n0+wn*64+ni*16+(lane>>4)*4
+  // ---- epilogue.  Accumulators (lane: C[m = ..+mi*16+(lane&15)][4 consecutive n]) go through a wave-private LDS tile
+  // [64 m][64 n] so that global traffic is row-contiguous: one wave instruction covers 4 rows x 256 B (fp32) /
+  // 128 B (bf16) of C and of the aux operand, instead of 16 rows x 64/32 B.
+  constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
+  float* stage = (float*)smem + wave * (64 * LDW);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][mi];
   const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
   const long cbase = (long)batch * g.sC;
   const long xbase = (long)batch * g.sAux;
   const bool vec_ok = ((g.ldc & 3) == 0);
+  const int er = lane >> 4, ec = (lane & 15) * 4;  // this lane's row-within-quad and column offset
+  const int n4 = n0 + wn * 64 + ec;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && (!SPLITK || (ks == 0 && !g.ws))) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + frow;
-    if (m >= g.M) continue;
-    const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n4 = n0 + wn * 64 + ni * 16 + fg * 4;
-      if (n4 >= g.N) continue;
+    for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
+  }
+  const bool full = (n4 + 3 < g.N);
+  if (n4 < g.N) {
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + er;
+      const int m = m0 + wm * 64 + row;
+      if (m >= g.M) continue;
+      const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
+      const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
       float v[4], pre[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] * g.alpha;
-      const bool full = (n4 + 3 < g.N);
+      for (int r = 0; r < 4; ++r) v[r] = (a4[r] * g.alpha + bv[r]) * rs;
       if (SPLITK) {
         if (g.ws) {  // plain 16-byte stores of the partial tile; folded into out_f32 by splitk_reduce_kernel
-          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
-          continue;
-        }
-        if (ks == 0 && bias)
+          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
           for (int r = 0; r < 4; ++r)
-            if (n4 + r < g.N) v[r] += bias[n4 + r];
-        for (int r = 0; r < 4; ++r)
-          if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r] * rs);
+            if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r]);
+        }
         continue;
-      }
-      if (bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (n4 + r < g.N) ? bias[n4 + r] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] *= rs;
         pre[r] = v[r];
         if (ACT == FBL_ACT_GELU) v[r] = gelu_erf(v[r]);
         else if (ACT == FBL_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
       }
       if (AUX != FBL_AUX_NONE) {
         const long ao = xbase + (long)m * g.ld_aux + n4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (AUX == FBL_AUX_ADD_F32) {
+          if (full && (g.ld_aux & 3) == 0) {
+            const f32x4 t = *(const f32x4*)((const float*)g.aux + ao);
+            x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
+          } else {
+            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = ((const float*)g.aux)[ao + r];
+          }
+        } else {
+          if (full && (g.ld_aux & 3) == 0) {
+            const bf16x4 t = *(const bf16x4*)((const bf16*)g.aux + ao);
+            x[0] = bf2f(t[0]); x[1] = bf2f(t[1]); x[2] = bf2f(t[2]); x[3] = bf2f(t[3]);
+          } else {
+            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = bf2f(((const bf16*)g.aux)[ao + r]);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (n4 + r >= g.N) break;
-          if (AUX == FBL_AUX_ADD_F32) v[r] += ((const float*)g.aux)[ao + r];
-          else if (AUX == FBL_AUX_ADD_BF16) v[r] += bf2f(((const bf16*)g.aux)[ao + r]);
-          else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(bf2f(((const bf16*)g.aux)[ao + r]));
-          else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (bf2f(((const bf16*)g.aux)[ao + r]) > 0.f) ? v[r] : 0.f;
+          if (AUX == FBL_AUX_ADD_F32 || AUX == FBL_AUX_ADD_BF16) v[r] += x[r];
+          else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(x[r]);
+          else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (x[r] > 0.f) ? v[r] : 0.f;
         }
       }
       const long co = cbase + (long)m * g.ldc + n4;
@@ -268,7 +289,8 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
-  const int smem_bytes = 2 * STAGE_BYTES;
+  const int smem_bytes = SMEM_BYTES;
+  static_assert(SMEM_BYTES >= 2 * STAGE_BYTES, "LDS must hold both pipeline stages");
 #define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                                                                       \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \

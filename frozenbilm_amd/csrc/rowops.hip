@@ -174,12 +174,12 @@ template <int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   constexpr int VEC = (EPL % 4 == 0) ? 4 : ((EPL % 2 == 0) ? 2 : 1);
   constexpr int NIT = EPL / VEC;
-  __shared__ float red[4 * 2 * 64 * EPL];  // [wave][2][H]
+  __shared__ float red[4 * 3 * 64 * EPL];  // [wave][3][H]: dgamma, dbeta, colsum(dy)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H;
-  float dg[EPL], db[EPL], gam[EPL];
+  float dg[EPL], db[EPL], dys[EPL], gam[EPL];
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) dg[e] = db[e] = 0.f;
+  for (int e = 0; e < EPL; ++e) dg[e] = db[e] = dys[e] = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) ldf<VEC>(a.gamma + (it * 64 + lane) * VEC, gam + it * VEC);
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         dt[c] = rstd * (g[e] - s1 - xh[e] * s2);
         dy[c] = dt[c];
         if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+        dys[e] += dy[c];
       }
       if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
       if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * H + col, dy);
@@ -230,16 +231,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     const int col = (it * 64 + lane) * VEC;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-      red[(wave * 2 + 0) * H + col + c] = dg[it * VEC + c];
-      red[(wave * 2 + 1) * H + col + c] = db[it * VEC + c];
+      red[(wave * 3 + 0) * H + col + c] = dg[it * VEC + c];
+      red[(wave * 3 + 1) * H + col + c] = db[it * VEC + c];
+      red[(wave * 3 + 2) * H + col + c] = dys[it * VEC + c];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[w * 2 * H + i];
-    a.ws[(long)blockIdx.x * 2 * H + i] = s;
+    for (int w = 0; w < 4; ++w) s += red[w * 3 * H + i];
+    a.ws[(long)blockIdx.x * 3 * H + i] = s;
   }
 }
 // fold [nblk][ncols] partial sums: a block owns 16 columns, its 16 row-groups stride over the partial rows
@@ -257,12 +259,14 @@ __device__ __forceinline__ float fold16(const float* ws, int nblk, int ncols, in
   }
   return s;
 }
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta,
+                                                          float* dysum) {
   const int i = blockIdx.x * 16 + (threadIdx.x & 15);
-  const float s = fold16(ws, nblk, 2 * H, i);
-  if ((threadIdx.x >> 4) == 0 && i < 2 * H) {
-    if (i < H) dgamma[i] += s;
-    else dbeta[i - H] += s;
+  const float s = fold16(ws, nblk, 3 * H, i);
+  if ((threadIdx.x >> 4) == 0 && i < 3 * H) {
+    if (i < H) { if (dgamma) dgamma[i] += s; }
+    else if (i < 2 * H) { if (dbeta) dbeta[i - H] += s; }
+    else if (dysum) dysum[i - 2 * H] += s;
   }
 }
 
@@ -546,10 +550,11 @@ extern "C" int fbl_ln_materialize(const float* t, const float* stats, const floa
   return 0;
 }
 
-extern "C" int64_t fbl_ln_bwd_ws_floats(int H) { return (int64_t)LNB_BLOCKS * 2 * H; }
+extern "C" int64_t fbl_ln_bwd_ws_floats(int H) { return (int64_t)LNB_BLOCKS * 3 * H; }
 extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats,
                           const float* gamma, float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16,
-                          float* out_dy_f32, float* dgamma, float* dbeta, float* ws, int N, int H, void* stream) {
+                          float* out_dy_f32, float* dgamma, float* dbeta, float* dysum, float* ws, int N, int H,
+                          void* stream) {
   if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
   if (N <= 0) return 0;
   LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H};
@@ -558,9 +563,9 @@ extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float
   dim3 grid(nblk);
   FBL_EPL_DISPATCH(H, ln_bwd_kernel, grid, a, (hipStream_t)stream);
   FBL_CHECK_LAUNCH();
-  if (dgamma && dbeta) {
-    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
-                       dgamma, dbeta);
+  if (dgamma || dbeta || dysum) {
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
+                       dgamma, dbeta, dysum);
     FBL_CHECK_LAUNCH();
   }
   return 0;

@@ -480,12 +480,14 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True):
+    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True, dysum=None):
+        """dysum: optional [H] accumulator for colsum(dy) = the bias gradient of whatever produced y (adapter up.bias)."""
         N, H = dout.shape
         dt = torch.empty(N, H, dtype=F32, device=self.dev)
         dyb = torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None
         L.ln_bwd(dout, norm.t, norm.stats, norm.gamma, rowmask=norm.rowmask, p_drop=p_drop, seed=seed, out_dt=dt,
-                 out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], ws=self._ln_ws)
+                 out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], dysum=dysum,
+                 ws=self._ln_ws)
         return dt, dyb
 
     def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed):
@@ -512,8 +514,7 @@ class Engine:
         nm = ent["name"]
         L.gemm(dyT, zT, out_f32=self.G[nm + ".up.weight"], N=A, splitk=sk, ws=self.sk_ws)      # dWu[H,A] += dy^T z
         L.gemm(dzT, xT, out_f32=self.G[nm + ".down.weight"], M=A, splitk=sk, ws=self.sk_ws)    # dWd[A,H] += dz^T x
-        L.colsum(dyb, self.G[nm + ".up.bias"], self._cs_ws)
-        L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)
+        L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)  # up.bias grad = colsum(dy) comes from ln_bwd
         return dx
 
     def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
@@ -524,7 +525,8 @@ class Engine:
         H, I, dev = self.H, self.I, self.dev
         N = dout.shape[0]
         p = f"deberta.encoder.layer.{li}"
-        dt2, dy2 = self._ln_bwd(p + ".output.LayerNorm", dout, sv.ln2, run.p_hid, sv.seed_ln2)
+        dt2, dy2 = self._ln_bwd(p + ".output.LayerNorm", dout, sv.ln2, run.p_hid, sv.seed_ln2,
+                                dysum=self.G[ad["a2"]["name"] + ".up.bias"] if "a2" in ad else None)
         df = dy2
         if "a2" in ad:
             df = self._adapter_bwd(run, ad["a2"], dy2, sv.z2, sv.fb, sv.seed_ad2)
@@ -533,7 +535,8 @@ class Engine:
         da = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dh, W["WiT"], aux=dt2, aux_kind=L.AUX_ADD_F32, out_f32=da)
         del dh
-        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1)
+        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
+                                dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None)
         do = dy1
         if "a1" in ad:
             do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)

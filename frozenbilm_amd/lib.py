@@ -29,7 +29,7 @@ SIGNATURES = {
                         _vp]),
     "fbl_ln_materialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "fbl_ln_bwd_ws_floats": (_l, [_i]),
-    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fbl_im2col3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "fbl_col2im3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
@@ -197,11 +197,11 @@ def ln_bwd_ws(H, device):
 
 
 def ln_bwd(dout, t, stats, gamma, *, rowmask=None, p_drop=0.0, seed=0, out_dt=None, out_dy_bf16=None, out_dy_f32=None,
-           dgamma=None, dbeta=None, ws=None):
+           dgamma=None, dbeta=None, dysum=None, ws=None):
     N, H = t.shape
     assert dout.is_contiguous() and t.is_contiguous()
     _chk(load().fbl_ln_bwd(_p(dout), _p(rowmask), _p(t), _p(stats), _p(gamma), float(p_drop), int(seed), _p(out_dt),
-                           _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(ws), N, H, _stream()),
+                           _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(dysum), _p(ws), N, H, _stream()),
          "fbl_ln_bwd")
 
 

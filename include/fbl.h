@@ -71,13 +71,14 @@ int fbl_ln_materialize(const float* t, const float* stats, const float* gamma, c
 
 /* Backward of fbl_ln_fwd.  dout fp32 [N,H] = grad of the LN output (after rowmask).
  *  out_dt fp32 [N,H]: grad wrt t (= grad of the residual branch).  out_dy_bf16/out_dy_f32: grad wrt y (dropout mask
- *  regenerated from seed), optional.  dgamma/dbeta [H] are ACCUMULATED (+=) deterministically via `ws`
- *  (fp32 workspace of fbl_ln_bwd_ws_floats(H) floats).
+ *  regenerated from seed), optional.  dgamma/dbeta [H] and dysum [H] (= column sums of dy: the bias gradient of the
+ *  layer that produced y) are ACCUMULATED (+=) deterministically via `ws` (fbl_ln_bwd_ws_floats(H) floats); each may
+ *  be NULL.
  * ref: autograd of torch.nn.LayerNorm + XDropout.backward (model/deberta.py:185-190). */
 int64_t fbl_ln_bwd_ws_floats(int H);
 int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats, const float* gamma,
                float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16, float* out_dy_f32, float* dgamma,
-               float* dbeta, float* ws, int N, int H, void* stream);
+               float* dbeta, float* dysum, float* ws, int N, int H, void* stream);
 
 /* out[n, k*H + c] = x[b, s+k-1, c] (0 outside the sequence), n = b*S+s, k in {0,1,2}: im2col for the 3-tap conv.
  * ref: model/deberta.py:396-400 (Conv1d k=3 pad=1 over the sequence axis). */

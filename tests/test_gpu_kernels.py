@@ -172,8 +172,11 @@ def test_ln_fwd_bwd(L, H):
     dg0, db0 = rnd(H, seed=10), rnd(H, seed=11)
     dg, db = dg0.clone(), db0.clone()
     dt = torch.empty(N, H, device=DEV); dyb = torch.empty(N, H, dtype=BF16, device=DEV)
-    L.ln_bwd(dout, t, st, g, rowmask=rowmask, out_dt=dt, out_dy_bf16=dyb, dgamma=dg, dbeta=db, ws=L.ln_bwd_ws(H, DEV))
+    dys = torch.ones(H, device=DEV)
+    L.ln_bwd(dout, t, st, g, rowmask=rowmask, out_dt=dt, out_dy_bf16=dyb, dgamma=dg, dbeta=db, dysum=dys,
+             ws=L.ln_bwd_ws(H, DEV))
     close(dt, tt.grad, 1e-4, 1e-4, "dt")
+    close(dys - 1.0, tt.grad.sum(0), 1e-4, 1e-3, "colsum(dy)")
     close(dyb, tt.grad, 1e-2, 1e-2, "dy bf16")
     xh = (tt.detach() - tt.detach().mean(1, keepdim=True)) * st[:, 1:2]
     close(dg - dg0, (dout * rowmask[:, None] * xh).sum(0), 1e-4, 1e-3, "dgamma")
