@@ -44,18 +44,23 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
     L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
+    # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
+    from .model.relpos import rel_index_vector
+    rv = rel_index_vector(S, eng.cfg.position_buckets, eng.cfg.max_rel, eng.cfg.att_span) if hasattr(eng, "cfg") else None
+    rmin, rcnt = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1) if rv is not None else (0, span2)
     G1T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
     G2T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
-    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen)
-    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen)
+    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt)
+    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
+                            rcnt=rcnt)
     del dS, dST
     # position tables: fp32 [span2, 2H] laid out [dPQ | dPK]; head h writes columns h*64 .. h*64+63
     dpos = torch.zeros(span2, 2 * H, dtype=F32, device=dev)
     Kc = B * Sp
     sk = max(2, min(16, Kc // 1024))
-    o_pk = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), H)
-    o_pq = torch.as_strided(dpos, (nh, span2, 64), (64, 2 * H, 1), 0)
+    o_pk = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), H + rmin * 2 * H)
+    o_pq = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), rmin * 2 * H)
     ws = getattr(eng, "sk_ws", None)
-    L.gemm(G1T, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws)
-    L.gemm(G2T, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws)
+    L.gemm(G1T[:, rmin:rmin + rcnt], QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws)
+    L.gemm(G2T[:, rmin:rmin + rcnt], KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws)
     L.cast_bf16(dpos, dpqk)

@@ -296,6 +296,7 @@ struct ShearArgs {
   bf16* out; long ldout;                  // row-major, head h at col h*64
   bf16* GT;                               // [nh][span2][B][Sp]
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
+  int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
 };
 constexpr int C_YT = 0;                     // [64 d][72] bf16
 constexpr int C_IDX = C_YT + 64 * LDV * 2;  // int16[1024]
@@ -410,8 +411,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
   }
   // ---- G^T[h][r][b][r0 .. r0+31] (bf16), zero outside [rbase, rbase+Wg): thread -> (r, 8-row chunk)
-  for (int id = tid; id < a.span2 * 4; id += 128) {
-    const int r = id >> 2, ch = id & 3;
+  for (int id = tid; id < a.rcnt * 4; id += 128) {
+    const int r = a.rmin + (id >> 2), ch = id & 3;
     const int gr = r - rbase;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (gr >= 0 && gr < a.Wg) {
@@ -460,7 +461,8 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
                                          int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen, void* out,
-                                         int64_t ldout, void* GT, int B, int S, int Sp, int nh, int span2, void* stream) {
+                                         int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int B, int S, int Sp, int nh,
+                                         int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
@@ -468,8 +470,9 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   int Wg = S + 31 + 7;
   if (Wg > span2) Wg = span2;
   Wg = (Wg + 31) / 32 * 32;
+  if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, (bf16*)out, ldout, (bf16*)GT,
-              B, S, Sp, nh, span2, Wg};
+              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt};
   const int smem_bytes = C_G + 32 * (Wg + 4) * 4;
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {

@@ -236,6 +236,99 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "TN" variant for the trainable-weight gradients:  C[M,N] += sum_k A[k,m] * B[k,n]   (A [K,M], B [K,N] row-major, the
+// contraction runs over ROWS: dW = X^T . dY without materialising X^T / dY^T in HBM).  128x128x64 tile, 4 waves.
+// Tiles are staged row-major in LDS (coalesced 16-byte global loads, next tile prefetched into registers) and the
+// MFMA fragments -- 8 consecutive k for one m -- are gathered with 8 ds_read_u16 each (conflict-free: the 16 lanes of
+// a group read 16 consecutive columns).  LDS-read bound at ~1/2 the NT rate, which is fine: these GEMMs are ~5 GFLOP.
+// Always split-K with a workspace fold (accumulates into C).
+struct GemmTnArgs {
+  const bf16* A; const bf16* B; long lda, ldb;
+  int M, N, K;
+  float* ws; int Nw;  // partials [splitk][M][Nw]
+  int splitk, tiles_m, tiles_n;
+};
+constexpr int TN_LD = 136;  // bf16 row stride of the staged [64 k][128 cols] tiles (272 B: 16B-aligned rows)
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16 sA[64 * TN_LD];
+  __shared__ __attribute__((aligned(16))) bf16 sB[64 * TN_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int ks = blockIdx.y;
+  const int nk = (g.K + 63) / 64;
+  const int per = (nk + g.splitk - 1) / g.splitk;
+  const int kt0 = ks * per, kt1 = min(nk, kt0 + per);
+  const int frow = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging role: 64 rows x 16 chunks(8 cols) per operand = 1024 chunks -> 4 per thread
+  bf16x8 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int id = tid + t * 256;
+      const int r = id >> 4, ch = id & 15;
+      const int k = kt * 64 + r;
+      const bool kok = k < g.K;
+      const int ca = m0 + ch * 8, cb = n0 + ch * 8;
+      ra[t] = (kok && ca + 8 <= g.M) ? *(const bf16x8*)(g.A + (long)k * g.lda + ca) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      rb[t] = (kok && cb + 8 <= g.N) ? *(const bf16x8*)(g.B + (long)k * g.ldb + cb) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  if (kt0 < kt1) load_tile(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int id = tid + t * 256;
+      *(bf16x8*)(sA + (id >> 4) * TN_LD + (id & 15) * 8) = ra[t];
+      *(bf16x8*)(sB + (id >> 4) * TN_LD + (id & 15) * 8) = rb[t];
+    }
+    __syncthreads();
+    if (kt + 1 < kt1) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bfg[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kr = (s * 32 + fg * 8 + e) * TN_LD;
+          af[i][e] = sA[kr + wm * 64 + i * 16 + frow];
+          bfg[i][e] = sB[kr + wn * 64 + i * 16 + frow];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // partial tile -> workspace (lane owns C[m][4 consecutive n]); rows/cols beyond M/N are skipped
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + frow;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n4 = n0 + wn * 64 + ni * 16 + fg * 4;
+      if (n4 >= g.N) continue;
+      *(f32x4*)(g.ws + (((long)ks * g.M + m) * g.Nw + n4)) = acc[ni][mi];
+    }
+  }
+}
+
 // out[b][m][n] += sum_ks ws[b][ks][m][n]   (deterministic split-K fold)
 __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, int Nw, float* out, long ldc, long sC) {
   const int b = blockIdx.y;
@@ -318,6 +411,28 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream,
                        (const float*)g.ws, splitk, M, N, Nw, out_f32, (long)ldc, (long)strideC);
   }
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                                    float* out_f32, int64_t ldc, int splitk, float* splitk_ws, int64_t splitk_ws_floats,
+                                    void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if ((lda % 8) || (ldb % 8) || (M % 8) || (N % 8)) return FBL_ERR_ALIGN;
+  if (!out_f32 || !splitk_ws) return FBL_ERR_ARG;
+  if (splitk < 1) splitk = 1;
+  const int nk = (K + 63) / 64;
+  const int per = (nk + splitk - 1) / splitk;
+  splitk = (nk + per - 1) / per;
+  const int Nw = (N + 3) & ~3;
+  if ((int64_t)splitk * M * Nw > splitk_ws_floats) return FBL_ERR_ARG;
+  GemmTnArgs g{(const bf16*)A, (const bf16*)B, lda, ldb, M, N, K, splitk_ws, Nw, splitk, (M + 127) / 128, (N + 127) / 128};
+  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(g.tiles_m * g.tiles_n, splitk), dim3(256), 0, (hipStream_t)stream, g);
+  FBL_CHECK_LAUNCH();
+  const long nq = (long)M * (Nw >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)splitk_ws, splitk, M, N, Nw, out_f32, (long)ldc, 0L);
   FBL_CHECK_LAUNCH();
   return 0;
 }

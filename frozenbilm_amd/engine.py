@@ -501,19 +501,10 @@ class Engine:
         L.gemm(dyb, upT, alpha=inv_keep, aux=z, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=dz, N=A)
         dx = torch.empty(N, H, dtype=BF16, device=dev)
         L.gemm(dz, downT, aux=dyb, aux_kind=L.AUX_ADD_BF16, out_bf16=dx)
-        Np = _ru(N, 64)
-        dyT = torch.empty(H, Np, dtype=BF16, device=dev)
-        zT = torch.empty(Ap, Np, dtype=BF16, device=dev)
-        dzT = torch.empty(Ap, Np, dtype=BF16, device=dev)
-        xT = torch.empty(H, Np, dtype=BF16, device=dev)
-        L.transpose_to_bf16(dyb, dyT)
-        L.transpose_to_bf16(z, zT)
-        L.transpose_to_bf16(dz, dzT)
-        L.transpose_to_bf16(xin_b, xT)
-        sk = max(2, min(16, Np // 512))  # >= 2: the split-K path ACCUMULATES (atomicAdd) into the grad buffer
+        sk = max(2, min(16, N // 512))
         nm = ent["name"]
-        L.gemm(dyT, zT, out_f32=self.G[nm + ".up.weight"], N=A, splitk=sk, ws=self.sk_ws)      # dWu[H,A] += dy^T z
-        L.gemm(dzT, xT, out_f32=self.G[nm + ".down.weight"], M=A, splitk=sk, ws=self.sk_ws)    # dWd[A,H] += dz^T x
+        L.gemm_tn_acc(dyb, z, self.G[nm + ".up.weight"], self.sk_ws, N=A, splitk=sk)      # dWu[H,A] += dy^T z
+        L.gemm_tn_acc(dz, xin_b, self.G[nm + ".down.weight"], self.sk_ws, M=A, splitk=sk)  # dWd[A,H] += dz^T x
         L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)  # up.bias grad = colsum(dy) comes from ln_bwd
         return dx
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
                               _l, _l, _l, _i, _vp, _l, _vp]),
+    "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                         _vp]),
@@ -43,7 +44,7 @@ SIGNATURES = {
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i,
+    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
@@ -154,6 +155,18 @@ def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, a
                                    _p(aux), ld_aux, _p(out_f32), _p(out_bf16), _p(out_pre), ldc or 0, batch, sA, sB, sC,
                                    sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), _stream())
     _chk(code, "fbl_gemm_bf16_nt")
+
+
+def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):
+    """out[M,N] += A[:K,:M]^T @ B[:K,:N]  (A [K,M'], B [K,N'] row-major bf16; contraction over rows)."""
+    _req(A, torch.bfloat16, "A"); _req(B, torch.bfloat16, "B"); _req(out_f32, torch.float32, "out")
+    lda, ldb, ldc = _rows2d(A, "A"), _rows2d(B, "B"), _rows2d(out_f32, "out")
+    K = min(A.shape[0], B.shape[0]) if K is None else K
+    M = A.shape[1] if M is None else M
+    N = B.shape[1] if N is None else N
+    assert out_f32.shape[0] >= M and out_f32.shape[1] >= N
+    _chk(load().fbl_gemm_bf16_tn_acc(_p(A), lda, _p(B), ldb, M, N, K, _p(out_f32), ldc, splitk, _p(ws), ws.numel(),
+                                     _stream()), "fbl_gemm_bf16_tn_acc")
 
 
 # ------------------------------------------------------------------------------------------------ row ops
@@ -297,11 +310,13 @@ def disent_attn_bwd_ds(q, k, v, dO, dOT, pk, pq, relidx, mask, lse, Dv, scale, d
          "fbl_disent_attn_bwd_ds")
 
 
-def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None):
+def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None,
+                          rmin=0, rcnt=None):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
     _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(out), ldout,
-                                          _p(GT), B, S, Sp, nh, span2, _stream()), "fbl_disent_attn_bwd_shear")
+                                          _p(GT), rmin, span2 if rcnt is None else rcnt, B, S, Sp, nh, span2, _stream()),
+         "fbl_disent_attn_bwd_shear")
 
 
 def ce_fwd(logits, labels, V, row_lse, loss_sum_cnt):

@@ -45,6 +45,13 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
                      float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 
+/* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
+ * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
+ * (splitk_ws >= splitk*M*roundup(N,4) floats, required).  M, N, lda, ldb multiples of 8; K arbitrary.
+ * ref: autograd dW of model/adapter.py:38,42 and of linear_video (model/deberta.py:994). */
+int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, float* out_f32,
+                         int64_t ldc, int splitk, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
+
 /* t0[b, s, :] = s < T ? vproj[b*T + s, :] : E[ids[b, s-T], :]     (fp32).  vproj may be NULL (T = 0).
  * ref: model/deberta.py:1012-1016 (word_embeddings + cat with linear_video output). */
 int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H, float* out_t,
@@ -132,7 +139,8 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  *                              neg=1: out = dK = dS^T.Q + G2.PQ, G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]
  *                              X = dS / dS^T; YT = transposed K / Q (fbl_head_transpose strides); PT = transposed
  *                              PK / PQ [nh][64][span2]; also writes GT = G^T as bf16 [nh][span2][B][Sp], the operand of
- *                              the position-table gradient GEMM  dPK[h] = G1T[h] . QT[h]^T  (dPQ: G2T, KT). */
+ *                              the position-table gradient GEMM  dPK[h] = G1T[h] . QT[h]^T  (dPQ: G2T, KT); only rows
+ *                              [gt_rmin, gt_rmin+gt_rcnt) = the range of relidx are written (the others are 0). */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
@@ -142,7 +150,8 @@ int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t 
                            int S, int Sp, int nh, int span2, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
                               const void* PT, const int16_t* relidx, const int32_t* klen, void* out, int64_t ldout,
-                              void* GT, int B, int S, int Sp, int nh, int span2, void* stream);
+                              void* GT, int gt_rmin, int gt_rcnt, int B, int S, int Sp, int nh, int span2,
+                              void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */

@@ -126,6 +126,22 @@ def test_gemm_splitk_accumulates_and_batched(L):
     assert (out[:, :64] == 0).all()
 
 
+@pytest.mark.parametrize("K,M,N", [(8512, 1536, 192), (333, 192, 1536), (64, 16, 128), (1000, 128, 16)])
+def test_gemm_tn_accumulate(L, K, M, N):
+    """C += A^T B with row-major operands (contraction over rows): the dW form, no transposed copies."""
+    Mp, Np = (M + 63) // 64 * 64, (N + 63) // 64 * 64
+    A = torch.zeros(K, Mp, dtype=BF16, device=DEV); A[:, :M] = bf(rnd(K, M, seed=1))
+    B = torch.zeros(K, Np, dtype=BF16, device=DEV); B[:, :N] = bf(rnd(K, N, seed=2, scale=0.1))
+    out = torch.ones(M, N, dtype=F32, device=DEV)
+    ws = torch.empty(16 << 20, dtype=F32, device=DEV)
+    L.gemm_tn_acc(A, B, out, ws, M=M, N=N, splitk=8)
+    ref = 1.0 + A[:, :M].float().t() @ B[:, :N].float()
+    close(out, ref, 1e-4, 2e-3 * max(1.0, K / 1000), "gemm_tn")
+    out2 = torch.ones(M, N, dtype=F32, device=DEV)
+    L.gemm_tn_acc(A, B, out2, ws, M=M, N=N, splitk=8)
+    assert torch.equal(out, out2)
+
+
 def test_gemm_strided_views(L):
     """operands / outputs that are column slices of wider buffers (QKV packing)."""
     M, K = 150, 128
