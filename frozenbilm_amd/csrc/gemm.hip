@@ -15,11 +15,17 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
+constexpr int BK = 64;
 constexpr int NXCD = 8;
-constexpr int SMEM_BYTES = 4 * 64 * 68 * 4;  // max(2 stages x 32 KiB, 4 waves x 64x68 fp32 epilogue tiles) = 69632
+// Tile configurations (NW waves, wave grid WR x WC, each wave (MI*16) x 64 outputs; BM = BN = 32*NW):
+//   small: 128x128, 4 waves (2x2), MI=4  -> 69.6 KiB LDS, 2 workgroups/CU   (narrow / short GEMMs)
+//   big:   256x256, 8 waves (2x4), MI=8  -> 136 KiB LDS, 1 workgroup/CU     (1/3 fewer LDS bytes per MFMA)
+template <int NW> struct TileCfg {
+  static constexpr int BM = 32 * NW, BN = 32 * NW;
+  static constexpr int TILE_BYTES = BM * BK * 2;
+  static constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  static constexpr int SMEM_BYTES = (NW * 64 * 68 * 4 > 2 * STAGE_BYTES) ? NW * 64 * 68 * 4 : 2 * STAGE_BYTES;
+};
 
 struct GemmArgs {
   const bf16* A;
@@ -48,13 +54,18 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int ACT, int AUX, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+template <int NW, int ACT, int AUX, bool SPLITK>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+  using Cfg = TileCfg<NW>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int WC = NW / 2;        // waves along N (2 rows of waves along M)
+  constexpr int MI = BM / 2 / 16;   // 16-row MFMA tiles per wave along M (4 or 8); 4 tiles (64 cols) along N
+  constexpr int WROWS = MI * 16;    // rows of C per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WC, wn = wave % WC;
 
   // ---- tile mapping: XCD-aware (block b runs on XCD b%8) + grouped along M so neighbours share the B panel in L2
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   const bf16* b_src[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int row = (q * 4 + wave) * 8 + lrow;
+    const int row = (q * NW + wave) * 8 + lrow;
     const int am = min(m0 + row, g.M - 1);
     const int bn = min(n0 + row, g.N - 1);
     a_src[q] = A + (long)am * g.lda + lchunk * 8;
@@ -102,26 +113,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     const long koff = (long)kt * BK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int off = (q * 4 + wave) * 1024;
+      const int off = (q * NW + wave) * 1024;
       glds16(a_src[q] + koff, base + off);
       glds16(b_src[q] + koff, base + TILE_BYTES + off);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (bytes) inside a tile: row*128 + ((s*4 + lane>>4) ^ (row&7))*16
   const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
-  int a_off[4], b_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_off[i] = (wm * 64 + i * 16 + frow) * 128;
-    b_off[i] = TILE_BYTES + (wn * 64 + i * 16 + frow) * 128;
-  }
+  const int a_off0 = (wm * WROWS + frow) * 128;                 // + i*16*128 per M tile
+  const int b_off0 = TILE_BYTES + (wn * 64 + frow) * 128;       // + i*16*128 per N tile
 
   issue(kt0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
@@ -132,16 +139,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int pc = ((s * 4 + fg) ^ fsw) * 16;
-      bf16x8 af[4], bfg[4];
+      bf16x8 af[MI], bfg[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)(base + a_off[i] + pc);
-        bfg[i] = *(const bf16x8*)(base + b_off[i] + pc);
-      }
+      for (int i = 0; i < 4; ++i) bfg[i] = *(const bf16x8*)(base + b_off0 + i * 2048 + pc);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + a_off0 + i * 2048 + pc);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
     __syncthreads();
@@ -152,10 +158,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   // 128 B (bf16) of C and of the aux operand, instead of 16 rows x 64/32 B.
   constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
   float* stage = (float*)smem + wave * (64 * LDW);
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][mi];
   const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
   const long cbase = (long)batch * g.sC;
   const long xbase = (long)batch * g.sAux;
@@ -168,11 +170,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
   }
   const bool full = (n4 + 3 < g.N);
-  if (n4 < g.N) {
+#pragma unroll
+  for (int half = 0; half < MI / 4; ++half) {  // the wave tile leaves in slabs of 64 rows
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+    if (n4 < g.N) {
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int row = it * 4 + er;
-      const int m = m0 + wm * 64 + row;
+      const int m = m0 + wm * WROWS + half * 64 + row;
       if (m >= g.M) continue;
       const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
       const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
           if (g.out_pre) g.out_pre[co + r] = f2bf(pre[r]);
         }
       }
+    }
     }
   }
 }
@@ -379,21 +389,28 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.splitk = splitk;
   g.ws = accumulate ? splitk_ws : nullptr;
   g.Nw = Nw;
-  g.tiles_m = (M + BM - 1) / BM;
-  g.tiles_n = (N + BN - 1) / BN;
+  // big tiles only where both dimensions fill them and the grid still covers the chip
+  const bool big = !accumulate && batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
+  const int BT = big ? 256 : 128;
+  g.tiles_m = (M + BT - 1) / BT;
+  g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
-  const int smem_bytes = SMEM_BYTES;
-  static_assert(SMEM_BYTES >= 2 * STAGE_BYTES, "LDS must hold both pipeline stages");
-#define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                                                                       \
+#define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_)                                                                \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \
-    auto kfn = gemm_bf16_nt_kernel<ACT_, AUX_, SK_>;                                                           \
+    auto kfn = gemm_bf16_nt_kernel<NW_, ACT_, AUX_, SK_>;                                                      \
+    constexpr int smem_bytes = TileCfg<NW_>::SMEM_BYTES;                                                       \
     if (!attr_set) {                                                                                           \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes); \
       if (e != hipSuccess) return (int)e;                                                                      \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), smem_bytes, (hipStream_t)stream, g);                              \
+    hipLaunchKernelGGL(kfn, grid, dim3(NW_ * 64), smem_bytes, (hipStream_t)stream, g);                         \
+  } while (0)
+#define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                         \
+  do {                                                           \
+    if (big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false);           \
+    else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_);                 \
   } while (0)
   if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
   else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
@@ -405,6 +422,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_POS_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_POS_BF16, false);
   else return FBL_ERR_ARG;
 #undef FBL_GEMM_LAUNCH
+#undef FBL_GEMM_LAUNCH_NW
   FBL_CHECK_LAUNCH();
   if (accumulate && g.ws) {
     const long nq = (long)M * (Nw >> 2);

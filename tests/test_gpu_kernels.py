@@ -39,7 +39,7 @@ def close(got, ref, rtol, atol, name=""):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 130, 128), (1000, 1536, 1536), (333, 192, 1536), (256, 4608, 192),
-                                   (130, 6, 64)])
+                                   (130, 6, 64), (4100, 2052, 128), (8512, 1536, 192)])  # last two: 256x256 tile config
 def test_gemm_plain_bias(L, M, N, K):
     A, B = bf(rnd(M, K, seed=1)).to(BF16), bf(rnd(N, K, seed=2, scale=0.05)).to(BF16)
     bias = rnd(N, seed=3)
@@ -64,8 +64,8 @@ def test_gemm_asymmetric_identity(L):
     assert torch.equal(o, B.float().t())
 
 
-def test_gemm_epilogues(L):
-    M, N, K = 300, 256, 128
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4100, 2052, 64)])  # small and big tile configurations
+def test_gemm_epilogues(L, M, N, K):
     A, B = bf(rnd(M, K, seed=1)).to(BF16), bf(rnd(N, K, seed=2, scale=0.1)).to(BF16)
     bias = rnd(N, seed=3)
     rows = (torch.arange(M, device=DEV) % 3 != 0).float()
