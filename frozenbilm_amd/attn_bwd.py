@@ -48,8 +48,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     from .model.relpos import rel_index_vector
     rv = rel_index_vector(S, eng.cfg.position_buckets, eng.cfg.max_rel, eng.cfg.att_span) if hasattr(eng, "cfg") else None
     rmin, rcnt = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1) if rv is not None else (0, span2)
-    G1T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
-    G2T = torch.empty(nh, span2, B * Sp, dtype=BF16, device=dev)
+    # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
+    G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+    G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
                             rcnt=rcnt)
@@ -61,6 +62,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     o_pk = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), H + rmin * 2 * H)
     o_pq = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), rmin * 2 * H)
     ws = getattr(eng, "sk_ws", None)
-    L.gemm(G1T[:, rmin:rmin + rcnt], QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws)
-    L.gemm(G2T[:, rmin:rmin + rcnt], KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws)
+    kblk = rcnt * 32  # elements between consecutive 32-wide k blocks of G^T
+    a1 = torch.as_strided(G1T, (nh, rcnt, 32), (G1T.stride(0), 32, 1))
+    a2 = torch.as_strided(G2T, (nh, rcnt, 32), (G2T.stride(0), 32, 1))
+    L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
+    L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
     L.cast_bf16(dpos, dpqk)

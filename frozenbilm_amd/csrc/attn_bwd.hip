@@ -294,7 +294,7 @@ struct ShearArgs {
   const int16_t* relidx;
   const int32_t* klen;
   bf16* out; long ldout;                  // row-major, head h at col h*64
-  bf16* GT;                               // [nh][span2][B][Sp]
+  bf16* GT;                               // [nh][B][Sp/32][rcnt][32]
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
   int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
 };
@@ -410,16 +410,20 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
   }
-  // ---- G^T[h][r][b][r0 .. r0+31] (bf16), zero outside [rbase, rbase+Wg): thread -> (r, 8-row chunk)
-  for (int id = tid; id < a.rcnt * 4; id += 128) {
-    const int r = a.rmin + (id >> 2), ch = id & 3;
-    const int gr = r - rbase;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (gr >= 0 && gr < a.Wg) {
+  // ---- G^T block of this workgroup: GT[h][b][tile][r][32 rows] (bf16), r = table row - rmin, zero outside
+  // [rbase, rbase+Wg).  One contiguous rcnt*64-byte block: thread -> (r, 8-row chunk) = consecutive 16 bytes.
+  {
+    bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
+    for (int id = tid; id < a.rcnt * 4; id += 128) {
+      const int r = a.rmin + (id >> 2), ch = id & 3;
+      const int gr = r - rbase;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (gr >= 0 && gr < a.Wg) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = f2bf(G[(ch * 8 + e) * LDG + gr]);
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(G[(ch * 8 + e) * LDG + gr]);
+      }
+      *(bf16x8*)(gt + (long)id * 8) = v;
     }
-    *(bf16x8*)(a.GT + (((long)h * a.span2 + r) * a.B + b) * Sp + r0 + ch * 8) = v;
   }
 }
 

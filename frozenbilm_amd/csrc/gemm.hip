@@ -47,6 +47,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
   int Nw;
+  long a_kblk;  // 0: A rows are K-contiguous.  >0: A is stored in 32-wide k blocks: A[m][k] at m*lda + (k/32)*a_kblk + k%32
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -105,16 +106,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
     const int row = (q * NW + wave) * 8 + lrow;
     const int am = min(m0 + row, g.M - 1);
     const int bn = min(n0 + row, g.N - 1);
-    a_src[q] = A + (long)am * g.lda + lchunk * 8;
+    a_src[q] = A + (long)am * g.lda + (g.a_kblk ? (long)(lchunk >> 2) * g.a_kblk + (lchunk & 3) * 8 : (long)lchunk * 8);
     b_src[q] = B + (long)bn * g.ldb + lchunk * 8;
   }
   auto issue = [&](int kt, int stage) {
     char* base = smem + stage * STAGE_BYTES;
     const long koff = (long)kt * BK;
+    const long koff_a = g.a_kblk ? (long)kt * 2 * g.a_kblk : koff;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int off = (q * NW + wave) * 1024;
-      glds16(a_src[q] + koff, base + off);
+      glds16(a_src[q] + koff_a, base + off);
       glds16(b_src[q] + koff, base + TILE_BYTES + off);
     }
   };
@@ -362,7 +364,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
                                 int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                                 int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
-                                int64_t splitk_ws_floats, void* stream) {
+                                int64_t splitk_ws_floats, int64_t a_kblock_stride, void* stream) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
@@ -389,6 +391,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.splitk = splitk;
   g.ws = accumulate ? splitk_ws : nullptr;
   g.Nw = Nw;
+  g.a_kblk = a_kblock_stride;
   // big tiles only where both dimensions fill them and the grid still covers the chip
   const bool big = !accumulate && batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
   const int BT = big ? 256 : 128;

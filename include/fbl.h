@@ -37,13 +37,15 @@ int fbl_abi_version(void);
  * batch > 1: strided batch (strides in elements).  splitk > 1: ACCUMULATE mode, out_f32 += A.B^T with the K range
  * split over `splitk` workgroup sets; partial tiles go to `splitk_ws` (>= batch*splitk*M*roundup(N,4) floats) and are
  * folded deterministically by a second tiny kernel; with splitk_ws == NULL (or too small) they are atomicAdd-ed.
+ * a_kblock_stride > 0: A is k-blocked, A[m][k] lives at m*lda + (k/32)*a_kblock_stride + k%32 (the G^T layout written
+ * by fbl_disent_attn_bwd_shear, lda = 32); 0 = plain K-contiguous rows.
  * ref: every nn.Linear on the path -- model/deberta.py:255,311,329,757-765,847-853,994,1545,1550;
  *      model/adapter.py:38,42; conv1d deberta.py:397 (as K=3H GEMM); and their autograd dX/dW. */
 int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
                      const float* rowscale, float alpha, int act, int aux_kind, const void* aux, int64_t ld_aux,
                      float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
-                     float* splitk_ws, int64_t splitk_ws_floats, void* stream);
+                     float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, void* stream);
 
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
@@ -138,9 +140,10 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  *  fbl_disent_attn_bwd_shear:  neg=0: out = dQ = dS.K + G1.PK,  G1[i,r] = sum_{j: idx(i-j)=r} dS[i,j]
  *                              neg=1: out = dK = dS^T.Q + G2.PQ, G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]
  *                              X = dS / dS^T; YT = transposed K / Q (fbl_head_transpose strides); PT = transposed
- *                              PK / PQ [nh][64][span2]; also writes GT = G^T as bf16 [nh][span2][B][Sp], the operand of
- *                              the position-table gradient GEMM  dPK[h] = G1T[h] . QT[h]^T  (dPQ: G2T, KT); only rows
- *                              [gt_rmin, gt_rmin+gt_rcnt) = the range of relidx are written (the others are 0). */
+ *                              PK / PQ [nh][64][span2]; also writes GT = G^T (bf16), the A operand of the position-table
+ *                              gradient GEMM dPK[h] = G1T[h] . QT[h]^T (dPQ: G2T, KT), k-blocked so that every
+ *                              workgroup writes one contiguous block: GT[h][b][t][r][32] with t = row/32, r in
+ *                              [0, gt_rcnt) standing for table row gt_rmin + r (the range of relidx; others are 0). */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
