@@ -67,4 +67,4 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     a2 = torch.as_strided(G2T, (nh, rcnt, 32), (G2T.stride(0), 32, 1))
     L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
     L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
-    L.cast_bf16(dpos, dpqk)
+    dpqk.copy_(dpos)  # fp32 -> bf16 into the (strided) tail rows of dqkv

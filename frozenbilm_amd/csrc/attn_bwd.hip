@@ -315,6 +315,20 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int row = r0 + rl;
   float* G = (float*)(smem + C_G);
   int16_t* idx = (int16_t*)(smem + C_IDX);
+  {  // rows entirely beyond the sample's last valid position: dS is zero there -> zero output rows, zero G^T block
+    const int kl0 = a.klen ? min(a.klen[b], S) : S;
+    if (r0 >= kl0) {
+      const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
+      for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
+      if (row < S) {
+        bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = (bf16x4){0, 0, 0, 0};
+      }
+      return;
+    }
+  }
   for (int t = tid; t < 32 * LDG; t += 128) G[t] = 0.f;
   for (int t = tid; t < 2 * S - 1; t += 128) idx[t] = a.relidx[t];
   // smallest reachable index for these 32 rows, aligned down to 8 so the PT fragments stay 16-byte aligned

@@ -52,6 +52,14 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   return cdf + x * 0.3989422804014327f * e;
 }
 
+// gelu(x) and gelu'(x) from one erf / one exp
+__device__ __forceinline__ void gelu_and_grad(float x, float* y, float* dy) {
+  float e;
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f, &e));
+  *y = x * cdf;
+  *dy = cdf + x * 0.3989422804014327f * e;
+}
+
 // Counter-based dropout RNG: keep decision is a pure function of (seed, element index), so backward
 // regenerates the mask instead of storing it.  Two rounds of a 64->32 bit multiply-xorshift mixer.
 __device__ __forceinline__ uint32_t fbl_hash(uint64_t seed, uint64_t idx) {

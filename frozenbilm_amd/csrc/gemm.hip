@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
         pre[r] = v[r];
         if (ACT == FBL_ACT_GELU) v[r] = gelu_erf(v[r]);
         else if (ACT == FBL_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        else if (ACT == FBL_ACT_GELU_GRAD) gelu_and_grad(pre[r], &v[r], &pre[r]);
       }
       if (AUX != FBL_AUX_NONE) {
         const long ao = xbase + (long)m * g.ld_aux + n4;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
           if (AUX == FBL_AUX_ADD_F32 || AUX == FBL_AUX_ADD_BF16) v[r] += x[r];
           else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(x[r]);
           else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (x[r] > 0.f) ? v[r] : 0.f;
+          else if (AUX == FBL_AUX_MUL_BF16) v[r] *= x[r];
         }
       }
       const long co = cbase + (long)m * g.ldc + n4;
@@ -418,6 +420,8 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
   else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_RELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_RELU, FBL_AUX_NONE, false);
+  else if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU_GRAD, FBL_AUX_NONE, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_BF16, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADD_F32, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADD_BF16, false);

@@ -47,6 +47,8 @@ class Stream:
     bf16: torch.Tensor
     norm: Optional[NormRef] = None
     plain: Optional[torch.Tensor] = None
+    full: Optional[torch.Tensor] = None  # [N + 2*span, H] buffer whose first N rows are `bf16`: the tail receives the
+    #                                      relative-position table R so that one GEMM yields Q|K|V and PQ|PK
 
 
 class Engine:
@@ -279,12 +281,13 @@ class Engine:
         return res
 
     # ------------------------------------------------------------------ forward
-    def _ln(self, run, name, *, y, resid: Optional[Stream], N, p_drop=0.0, rowmask=None, want_f32=False):
+    def _ln(self, run, name, *, y, resid: Optional[Stream], N, p_drop=0.0, rowmask=None, want_f32=False, tail=0):
         H = self.H
         g, b = self.P[name + ".weight"], self.P[name + ".bias"]
         t = torch.empty(N, H, dtype=F32, device=self.dev)
         stats = torch.empty(N, 2, dtype=F32, device=self.dev)
-        ob = torch.empty(N, H, dtype=BF16, device=self.dev)
+        full = torch.empty(N + tail, H, dtype=BF16, device=self.dev)
+        ob = full[:N]
         of = torch.empty(N, H, dtype=F32, device=self.dev) if want_f32 else None
         seed = run.next_seed() if p_drop > 0 else 0
         r_norm = resid.norm.as_args() if resid is not None and resid.norm is not None else None
@@ -292,7 +295,7 @@ class Engine:
         L.ln_fwd(y=y, p_drop=p_drop, seed=seed, r_plain=r_plain, r_norm=r_norm,
                  gamma=g, beta=b, eps=self.cfg.layer_norm_eps, rowmask=rowmask, out_t=t, out_stats=stats, out_bf16=ob,
                  out_f32=of, N=N, H=H)
-        return Stream(bf16=ob, norm=NormRef(t, stats, g, b, rowmask), plain=of), seed
+        return Stream(bf16=ob, norm=NormRef(t, stats, g, b, rowmask), plain=of, full=full if tail else None), seed
 
     def _adapter_fwd(self, run, ent, x_f32, x_bf16, N):
         """y = x + up(drop(relu(down(x))))  (model/adapter.py:33-45) as two epilogue-fused GEMMs."""
@@ -316,26 +319,33 @@ class Engine:
         Sp = _ru(S, 64)
         dev = self.dev
         sv = LayerSave(li=li, emd=q is not None)
-        qkv = torch.empty(N, 3 * H, dtype=BF16, device=dev)
-        if q is None:
-            L.gemm(kv.bf16, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
-        else:
-            L.gemm(q.bf16, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
-            L.gemm(kv.bf16, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
-        # shared-key position projections (:847-853): [PQ | PK] = R . [Wq | Wk]^T
-        Rl = Rb
-        if run.p_hid > 0:  # pos_dropout (:779)
+        # One GEMM gives Q|K|V for the N tokens AND the shared-key position projections [PQ|PK] = R.[Wq|Wk]^T (:847-853):
+        # the relative-position table R (pos_dropout applied, :779) is written into the P tail rows of the activations.
+        P_ = self.span2
+        if run.p_hid > 0:
             sv.seed_pos = run.next_seed()
-            Rl = torch.empty_like(Rb)
-            L.dropout_f32(run.R32, run.p_hid, sv.seed_pos, out_bf16=Rl)
-        pqk = torch.empty(self.span2, 2 * H, dtype=BF16, device=dev)
-        L.gemm(Rl, W["Wqkv"][: 2 * H], bias=W["bqkv"][: 2 * H], out_bf16=pqk)
+
+        def put_r(full):
+            if run.p_hid > 0:
+                L.dropout_f32(run.R32, run.p_hid, sv.seed_pos, out_bf16=full[N:])
+            else:
+                full[N:].copy_(Rb)
+
+        qkv = torch.empty(N + P_, 3 * H, dtype=BF16, device=dev)
+        put_r(kv.full)
+        if q is None:
+            L.gemm(kv.full, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
+        else:
+            put_r(q.full)
+            L.gemm(q.full, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
+            L.gemm(kv.full, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
+        pq, pk = qkv[N:, :H], qkv[N:, H:2 * H]
         vt = torch.empty(B, nh, 64, Sp, dtype=BF16, device=dev)
-        L.head_transpose(qkv[:, 2 * H:], vt, B, S, Sp, nh)
+        L.head_transpose(qkv[:N, 2 * H:], vt, B, S, Sp, nh)
         ctx = torch.empty(N, H, dtype=BF16, device=dev)
         lse = torch.empty(B, nh, S, dtype=F32, device=dev)
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
-        L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], self.relidx(S), run.mask_i32,
+        L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], vt, pk, pq, self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
                           seed=sv.seed_att, klen=run.klen)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
@@ -352,7 +362,8 @@ class Engine:
         # FFN: gelu(dense) -> dense -> adapter -> dropout -> LN(. + a)          (:310-313, :328-334)
         h = torch.empty(N, I, dtype=BF16, device=dev)
         hpre = torch.empty(N, I, dtype=BF16, device=dev) if run.save else None
-        L.gemm(a.bf16, W["Wi"], bias=W["bi"], act=L.ACT_GELU, out_bf16=h, out_pre=hpre)
+        # training: the epilogue stores gelu'(pre) (bf16) next to gelu(pre) so the backward epilogue is a plain multiply
+        L.gemm(a.bf16, W["Wi"], bias=W["bi"], act=L.ACT_GELU_GRAD if run.save else L.ACT_GELU, out_bf16=h, out_pre=hpre)
         f32 = torch.empty(N, H, dtype=F32, device=dev)
         fb = torch.empty(N, H, dtype=BF16, device=dev)
         L.gemm(h, W["Wd"], bias=W["bd"], out_f32=f32, out_bf16=fb)
@@ -360,9 +371,9 @@ class Engine:
         if "a2" in ad:
             y2, z2, sv.seed_ad2 = self._adapter_fwd(run, ad["a2"], f32, fb, N)
         out, sv.seed_ln2 = self._ln(run, p + ".output.LayerNorm", y=y2, resid=Stream(bf16=a.bf16, norm=a.norm), N=N,
-                                    p_drop=run.p_hid)
+                                    p_drop=run.p_hid, tail=self.span2)
         if run.save:
-            sv.qkv, sv.vt, sv.pqk, sv.ctx, sv.lse = qkv, vt, pqk, ctx, lse
+            sv.qkv, sv.vt, sv.pqk, sv.ctx, sv.lse = qkv[:N], vt, qkv[N:, : 2 * H], ctx, lse
             sv.ob, sv.z1, sv.ln1 = ob, z1, a.norm
             sv.hpre, sv.fb, sv.z2, sv.ln2 = hpre, fb, z2, out.norm
             run.layers.append(sv)
@@ -389,12 +400,12 @@ class Engine:
         L.embed_gather(input_ids, self.E32, vproj, T, t0)
         want_plain = run.p_hid > 0
         emb, _ = self._ln(run, "deberta.embeddings.LayerNorm", y=t0, resid=None, N=N, rowmask=run.mask_i32,
-                          want_f32=want_plain)
+                          want_f32=want_plain, tail=self.span2)
         run.emb_norm = emb.norm
         if want_plain:  # post-LN dropout: materialise x0
             run.seed_emb = run.next_seed()
             L.dropout_f32(emb.plain, run.p_hid, run.seed_emb, out_f32=emb.plain, out_bf16=emb.bf16)
-            emb = Stream(bf16=emb.bf16, plain=emb.plain)
+            emb = Stream(bf16=emb.bf16, plain=emb.plain, full=emb.full)
         # ---- relative-position table: R = LayerNorm_enc(rel_embeddings.weight)   (:474-478)
         r, _ = self._ln(run, "deberta.encoder.LayerNorm", y=self.rel_emb, resid=None, N=self.span2, want_f32=run.p_hid > 0)
         run.rel_norm, run.R32, Rb = r.norm, r.plain, r.bf16
@@ -417,9 +428,9 @@ class Engine:
         # ---- enhanced mask decoder (:1382-1412): q0 = pos_emb + hs[-2]; two passes of the last layer
         kv = hs[nL - 1]
         q32 = torch.empty(N, H, dtype=F32, device=dev)
-        qb = torch.empty(N, H, dtype=BF16, device=dev)
-        self._materialize(kv, add=self.pos_emb, S=S, out_f32=q32, out_bf16=qb)
-        q = Stream(bf16=qb, plain=q32)
+        qfull = torch.empty(N + self.span2, H, dtype=BF16, device=dev)
+        self._materialize(kv, add=self.pos_emb, S=S, out_f32=q32, out_bf16=qfull[:N])
+        q = Stream(bf16=qfull[:N], plain=q32, full=qfull)
         for _ in range(2):
             q = self._layer_fwd(run, nL - 1, kv, q, Rb)
         if want_hidden:
@@ -475,19 +486,26 @@ class Engine:
         y = torch.empty(N, H, dtype=F32, device=dev)
         run.seed_conv = run.next_seed() if run.p_hid > 0 else 0
         L.dropout_gelu_fwd(c, run.p_hid, run.seed_conv, y)
-        out, _ = self._ln(run, "deberta.encoder.conv.LayerNorm", y=y, resid=l0, N=N, rowmask=run.mask_i32)
+        out, _ = self._ln(run, "deberta.encoder.conv.LayerNorm", y=y, resid=l0, N=N, rowmask=run.mask_i32, tail=self.span2)
         run.conv_c, run.conv_norm = c, out.norm
         return out
 
     # ------------------------------------------------------------------ backward
-    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True, dysum=None):
-        """dysum: optional [H] accumulator for colsum(dy) = the bias gradient of whatever produced y (adapter up.bias)."""
+    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True, dysum=None, tail=0):
+        """dysum: optional [H] accumulator for colsum(dy) = the bias gradient of whatever produced y (adapter up.bias).
+        tail > 0: dt is the first N rows of a [N+tail, H] buffer whose tail is zeroed (aux operand of the dX GEMM that
+        also produces the position-table gradient rows); the full buffer is returned as third value."""
         N, H = dout.shape
-        dt = torch.empty(N, H, dtype=F32, device=self.dev)
+        dt_full = torch.empty(N + tail, H, dtype=F32, device=self.dev)
+        dt = dt_full[:N]
+        if tail:
+            dt_full[N:].zero_()
         dyb = torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None
         L.ln_bwd(dout, norm.t, norm.stats, norm.gamma, rowmask=norm.rowmask, p_drop=p_drop, seed=seed, out_dt=dt,
                  out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], dysum=dysum,
                  ws=self._ln_ws)
+        if tail:
+            return dt, dyb, dt_full
         return dt, dyb
 
     def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed):
@@ -522,45 +540,50 @@ class Engine:
         if "a2" in ad:
             df = self._adapter_bwd(run, ad["a2"], dy2, sv.z2, sv.fb, sv.seed_ad2)
         dh = torch.empty(N, I, dtype=BF16, device=dev)
-        L.gemm(df, W["WdT"], aux=sv.hpre, aux_kind=L.AUX_MUL_DGELU_BF16, out_bf16=dh)
+        L.gemm(df, W["WdT"], aux=sv.hpre, aux_kind=L.AUX_MUL_BF16, out_bf16=dh)  # sv.hpre holds gelu'(pre)
         da = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dh, W["WiT"], aux=dt2, aux_kind=L.AUX_ADD_F32, out_f32=da)
         del dh
-        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
-                                dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None)
+        dt1, dy1, dt1x = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
+                                      dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None,
+                                      tail=self.span2)
         do = dy1
         if "a1" in ad:
             do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
         dctx = torch.empty(N, H, dtype=BF16, device=dev)
         L.gemm(do, W["WoT"], out_bf16=dctx)
-        dqkv, dpqk = self._attn_bwd(run, sv, dctx)
-        # position tables: dR += [dPQ|dPK] . [Wq;Wk]   (through pos_dropout), accumulated over all layer executions
-        if run.p_hid > 0:
-            tmp = torch.empty(self.span2, H, dtype=F32, device=dev)
-            L.gemm(dpqk, W["WqkvT"][:, : 2 * H], out_f32=tmp)
-            L.dropout_f32(tmp, run.p_hid, sv.seed_pos, out_f32=tmp)
-            run.dR += tmp
-        else:
-            L.gemm(dpqk, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
+        dqkv = self._attn_bwd(run, sv, dctx)  # [N + P, 3H]: rows N.. hold [dPQ | dPK | 0]
+        # dX = dQKV . Wqkv.  The P tail rows give this execution's dR = [dPQ|dPK].[Wq;Wk] in the same GEMM; it goes
+        # back through pos_dropout and is accumulated over all layer executions.
+        P_ = self.span2
+
+        def take_dr(tail):
+            if run.p_hid > 0:
+                L.dropout_f32(tail, run.p_hid, sv.seed_pos, out_f32=tail)
+            run.dR.add_(tail)
+
         if not sv.emd:
-            dx = torch.empty(N, H, dtype=F32, device=dev)
-            L.gemm(dqkv, W["WqkvT"], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dx)
-            return dx, None
-        dq = torch.empty(N, H, dtype=F32, device=dev)
-        L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dq)
-        dkv = torch.empty(N, H, dtype=F32, device=dev)
+            dx = torch.empty(N + P_, H, dtype=F32, device=dev)
+            L.gemm(dqkv, W["WqkvT"], aux=dt1x, aux_kind=L.AUX_ADD_F32, out_f32=dx)
+            take_dr(dx[N:])
+            return dx[:N], None
+        dq = torch.empty(N + P_, H, dtype=F32, device=dev)
+        L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1x, aux_kind=L.AUX_ADD_F32, out_f32=dq)
+        take_dr(dq[N:])
+        dkv = torch.empty(N + P_, H, dtype=F32, device=dev)
         L.gemm(dqkv[:, H:], W["WqkvT"][:, H:], out_f32=dkv)
-        return dq, dkv
+        take_dr(dkv[N:])
+        return dq[:N], dkv[:N]
 
     def _attn_bwd(self, run, sv, dctx):
         B, S, H, nh = run.B, run.S, self.H, self.nh
         N = B * S
-        dqkv = torch.empty(N, 3 * H, dtype=BF16, device=self.dev)
-        dpqk = torch.empty(self.span2, 2 * H, dtype=BF16, device=self.dev)
+        dqkv = torch.empty(N + self.span2, 3 * H, dtype=BF16, device=self.dev)
         from .attn_bwd import disent_attn_bwd
 
-        disent_attn_bwd(self, run, sv, dctx, dqkv, dpqk)
-        return dqkv, dpqk
+        disent_attn_bwd(self, run, sv, dctx, dqkv[:N], dqkv[N:, : 2 * H])
+        dqkv[N:, 2 * H:].zero_()
+        return dqkv
 
     def backward(self, run, gloss: torch.Tensor):
         """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views)."""

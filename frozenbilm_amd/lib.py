@@ -14,8 +14,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfbl.so")
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
+AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 

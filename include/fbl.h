@@ -21,13 +21,19 @@ extern "C" {
 #define FBL_ERR_ALIGN (-2)
 #define FBL_ERR_ARG (-3)
 
-enum { FBL_ACT_NONE = 0, FBL_ACT_GELU = 1, FBL_ACT_RELU = 2 };
+enum {
+  FBL_ACT_NONE = 0,
+  FBL_ACT_GELU = 1,
+  FBL_ACT_RELU = 2,
+  FBL_ACT_GELU_GRAD = 3 /* out = gelu(v); out_pre receives gelu'(v) (not v): backward is then a plain multiply */
+};
 enum {
   FBL_AUX_NONE = 0,
   FBL_AUX_ADD_F32 = 1,        /* out = act(..) + aux_f32[m,n]                       (residual / grad accumulate) */
   FBL_AUX_ADD_BF16 = 2,       /* out = act(..) + aux_bf16[m,n]                                                    */
   FBL_AUX_MUL_DGELU_BF16 = 3, /* out = (..) * gelu'(aux_bf16[m,n])   (backward of deberta.py:310-313)            */
-  FBL_AUX_MUL_POS_BF16 = 4    /* out = (..) * (aux_bf16[m,n] > 0)    (backward of adapter.py:39 ReLU[+dropout])  */
+  FBL_AUX_MUL_POS_BF16 = 4,   /* out = (..) * (aux_bf16[m,n] > 0)    (backward of adapter.py:39 ReLU[+dropout])  */
+  FBL_AUX_MUL_BF16 = 5        /* out = (..) * aux_bf16[m,n]          (aux = gelu' saved by FBL_ACT_GELU_GRAD)    */
 };
 
 int fbl_abi_version(void);

@@ -95,6 +95,16 @@ def test_gemm_epilogues(L, M, N, K):
     F.gelu(x).sum().backward()
     L.gemm(A, B, aux=hp, aux_kind=L.AUX_MUL_DGELU_BF16, out_bf16=o16)
     close(o16, base * x.grad, 1e-2, 1e-2, "dgelu")
+    # gelu with saved derivative + plain bf16 multiply (training path)
+    dsave = torch.empty(M, N, dtype=BF16, device=DEV)
+    L.gemm(A, B, bias=bias, act=L.ACT_GELU_GRAD, out_bf16=o16, out_pre=dsave)
+    pz = (base + bias).requires_grad_(True)
+    gz = F.gelu(pz)
+    gz.sum().backward()
+    close(o16, gz, 1e-2, 1e-2, "gelu (grad variant)")
+    close(dsave, pz.grad, 1e-2, 1e-2, "saved gelu'")
+    L.gemm(A, B, aux=hp, aux_kind=L.AUX_MUL_BF16, out_bf16=o16)
+    close(o16, base * hp.float(), 1e-2, 1e-2, "mul_bf16")
     # positive mask with alpha
     L.gemm(A, B, alpha=1.25, aux=hp, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=o16)
     close(o16, 1.25 * base * (hp.float() > 0), 1e-2, 1e-2, "mul_pos")
