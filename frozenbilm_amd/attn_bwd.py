@@ -48,12 +48,15 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     from .model.relpos import rel_index_vector
     rv = rel_index_vector(S, eng.cfg.position_buckets, eng.cfg.max_rel, eng.cfg.att_span) if hasattr(eng, "cfg") else None
     rmin, rcnt = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1) if rv is not None else (0, span2)
+    # |i-j| < lin: identity buckets, relidx injective (model/deberta.py:578-589: mid = bucket_size // 2)
+    lin = 0 if rv is None else (eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30)
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
     G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
-    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt)
+    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
+                            lin=lin)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
-                            rcnt=rcnt)
+                            rcnt=rcnt, lin=lin)
     del dS, dST
     # position tables: fp32 [span2, 2H] laid out [dPQ | dPK]; head h writes columns h*64 .. h*64+63
     dpos = torch.zeros(span2, 2 * H, dtype=F32, device=dev)

@@ -297,6 +297,7 @@ struct ShearArgs {
   bf16* GT;                               // [nh][B][Sp/32][rcnt][32]
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
   int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
+  int lin;                                // |delta| < lin: idx(delta) is injective (identity buckets) -> plain stores
 };
 constexpr int C_YT = 0;                     // [64 d][72] bf16
 constexpr int C_IDX = C_YT + 64 * LDV * 2;  // int16[1024]
@@ -373,16 +374,23 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xv, acc[dt], 0, 0, 0);
       }
       int gi[8];
+      bool uniq[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int col = c0 + kk * 32 + g * 8 + e;
         const int dlt = NEG ? (col - row) : (row - col);
         gi[e] = clampi((int)idx[clampi(dlt + S - 1, 0, hi)] - rbase, 0, a.Wg - 1);
+        uniq[e] = abs(dlt) < a.lin;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {  // ~2/3 of dS is exactly 0 (padding / masks) and would pile up on a few clamped slots
+      for (int e = 0; e < 8; ++e) {  // ~2/3 of dS is exactly 0 (padding / masks) and is skipped
         const float x = bf2f(xv[e]);
-        if (x != 0.f) atomicAdd(&G[rl * LDG + gi[e]], x);
+        if (x != 0.f) {
+          // identity-bucket region: (row, col) -> slot is injective and G starts at 0, so a plain store is exact;
+          // LDS fp32 atomics (~190 cycles per wave instruction) are kept for the log-bucket region only
+          if (uniq[e]) G[rl * LDG + gi[e]] = x;
+          else atomicAdd(&G[rl * LDG + gi[e]], x);
+        }
       }
     }
     __syncthreads();
@@ -479,8 +487,8 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
                                          int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen, void* out,
-                                         int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int B, int S, int Sp, int nh,
-                                         int span2, void* stream) {
+                                         int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
+                                         int Sp, int nh, int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
@@ -490,7 +498,7 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   Wg = (Wg + 31) / 32 * 32;
   if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, (bf16*)out, ldout, (bf16*)GT,
-              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt};
+              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span};
   const int smem_bytes = C_G + 32 * (Wg + 4) * 4;
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {

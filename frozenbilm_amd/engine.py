@@ -608,8 +608,9 @@ class Engine:
             else:
                 tableT = torch.zeros(H, Vp, dtype=BF16, device=dev)
                 tableT[:, :Vout] = self.Ansb.t()
-            dhl = torch.empty(R, H, dtype=F32, device=dev)
-            L.gemm(dlog, tableT, out_f32=dhl)
+            # [R x H x Vp]: few rows, K = 128128 -> split-K so the grid covers the chip (accumulates into zeros)
+            dhl = torch.zeros(R, H, dtype=F32, device=dev)
+            L.gemm(dlog, tableT, out_f32=dhl, splitk=max(2, min(16, Vp // 8192)), ws=self.sk_ws)
             del dlog
             rl = rows.long()
             hn = run.head_norm

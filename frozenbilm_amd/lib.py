@@ -44,7 +44,7 @@ SIGNATURES = {
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i,
+    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
@@ -313,11 +313,11 @@ def disent_attn_bwd_ds(q, k, v, dO, dOT, pk, pq, relidx, mask, lse, Dv, scale, d
 
 
 def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None,
-                          rmin=0, rcnt=None):
+                          rmin=0, rcnt=None, lin=0):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
     _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(out), ldout,
-                                          _p(GT), rmin, span2 if rcnt is None else rcnt, B, S, Sp, nh, span2, _stream()),
+                                          _p(GT), rmin, span2 if rcnt is None else rcnt, int(lin), B, S, Sp, nh, span2, _stream()),
          "fbl_disent_attn_bwd_shear")
 
 

@@ -149,7 +149,9 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  *                              PK / PQ [nh][64][span2]; also writes GT = G^T (bf16), the A operand of the position-table
  *                              gradient GEMM dPK[h] = G1T[h] . QT[h]^T (dPQ: G2T, KT), k-blocked so that every
  *                              workgroup writes one contiguous block: GT[h][b][t][r][32] with t = row/32, r in
- *                              [0, gt_rcnt) standing for table row gt_rmin + r (the range of relidx; others are 0). */
+ *                              [0, gt_rcnt) standing for table row gt_rmin + r (the range of relidx; others are 0).
+ *                              lin_span: |i-j| < lin_span => relidx is injective there (identity buckets, = position_buckets/2;
+ *                              0 if unknown): those entries are scattered with plain LDS stores instead of atomics. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
@@ -159,8 +161,8 @@ int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t 
                            int S, int Sp, int nh, int span2, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
                               const void* PT, const int16_t* relidx, const int32_t* klen, void* out, int64_t ldout,
-                              void* GT, int gt_rmin, int gt_rcnt, int B, int S, int Sp, int nh, int span2,
-                              void* stream);
+                              void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
+                              int span2, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */

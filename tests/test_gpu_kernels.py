@@ -518,6 +518,8 @@ def test_attention_bwd(L, B, S, nh):
     eng, run, sv = E(), E(), E()
     eng.H, eng.nh, eng.span2, eng.dev = H, nh, pqk.shape[0], torch.device(DEV)
     eng.relidx = lambda S_: relidx
+    import types as _t
+    eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
     run.klen = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 0
