@@ -10,6 +10,8 @@
 // address (LDS-DMA destinations are lane-linear) and again on the ds_read_b128 side -> conflict-free fragment reads.
 // MFMA operands are swapped (weights as "A", activations as "B") so each lane owns 4 consecutive output columns
 // -> 16-byte fp32 / 8-byte bf16 epilogue stores.
+#include <stdlib.h>
+
 #include "fbl_common.h"
 #include "../../include/fbl.h"
 
@@ -55,7 +57,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NW, int ACT, int AUX, bool SPLITK>
+template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   using Cfg = TileCfg<NW>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
@@ -132,27 +134,69 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
   const int a_off0 = (wm * WROWS + frow) * 128;                 // + i*16*128 per M tile
   const int b_off0 = TILE_BYTES + (wn * 64 + frow) * 128;       // + i*16*128 per N tile
 
+  auto mfma_block = [&](const bf16x8* af, const bf16x8* bfg) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[ni], af[mi], acc[ni][mi], 0, 0, 0);
+  };
+  auto read_frags = [&](const char* base, int s_, bf16x8* af, bf16x8* bfg) {
+    const int pc = ((s_ * 4 + fg) ^ fsw) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bfg[i] = *(const bf16x8*)(base + b_off0 + i * 2048 + pc);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + a_off0 + i * 2048 + pc);
+  };
+  if constexpr (NW == 8 && (SCHED == 1 || SCHED == 4)) {
+    // ---- counted-vmcnt schedule: every tile is requested TWO K-steps before it is consumed (raw s_barrier +
+    // explicit s_waitcnt: __syncthreads() would drain the in-flight DMA).
+    issue(kt0, 0);
+    if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int stage = (kt - kt0) & 1;
+      const char* base = smem + stage * STAGE_BYTES;
+      if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      bf16x8 af0[MI], bf0[4], af1[MI], bf1[4];
+      read_frags(base, 0, af0, bf0);
+      if constexpr (SCHED == 1) mfma_block(af0, bf0);
+      read_frags(base, 1, af1, bf1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of this stage is in registers
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < kt1) issue(kt + 2, stage);
+      if constexpr (SCHED == 4) mfma_block(af0, bf0);
+      mfma_block(af1, bf1);
+    }
+    __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
+  } else {
   issue(kt0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
   for (int kt = kt0; kt < kt1; ++kt) {
     const int stage = (kt - kt0) & 1;
     if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
     const char* base = smem + stage * STAGE_BYTES;
+    if constexpr (SCHED == 2) {  // all 24 fragment reads first, then 64 MFMAs
+      bf16x8 af0[MI], bf0[4], af1[MI], bf1[4];
+      read_frags(base, 0, af0, bf0);
+      read_frags(base, 1, af1, bf1);
+      mfma_block(af0, bf0);
+      mfma_block(af1, bf1);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int pc = ((s * 4 + fg) ^ fsw) * 16;
-      bf16x8 af[MI], bfg[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bfg[i] = *(const bf16x8*)(base + b_off0 + i * 2048 + pc);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + a_off0 + i * 2048 + pc);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[ni], af[mi], acc[ni][mi], 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[MI], bfg[4];
+        read_frags(base, s, af, bfg);
+        if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(1);
+        mfma_block(af, bfg);
+        if constexpr (SCHED == 3) __builtin_amdgcn_s_setprio(0);
+      }
     }
     __syncthreads();
+  }
   }
 
   // ---- epilogue.  Accumulators (lane: C[m = ..+mi*16+(lane&15)][4 consecutive n]) go through a wave-private LDS tile
@@ -417,6 +461,27 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     if (big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false);           \
     else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_);                 \
   } while (0)
+#define FBL_GEMM_LAUNCH_SCHED(SCHED_)                                                                          \
+  do {                                                                                                         \
+    static bool attr_set = false;                                                                              \
+    auto kfn = gemm_bf16_nt_kernel<8, FBL_ACT_NONE, FBL_AUX_NONE, false, SCHED_>;                              \
+    constexpr int smem_bytes = TileCfg<8>::SMEM_BYTES;                                                         \
+    if (!attr_set) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes); \
+      if (e != hipSuccess) return (int)e;                                                                      \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), smem_bytes, (hipStream_t)stream, g);                              \
+  } while (0)
+  static const int exp_sched = getenv("FBL_GEMM_SCHED") ? atoi(getenv("FBL_GEMM_SCHED")) : 0;
+  if (big && exp_sched > 0 && act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) {  // experiment switch (plain epilogue)
+    if (exp_sched == 1) FBL_GEMM_LAUNCH_SCHED(1);
+    else if (exp_sched == 2) FBL_GEMM_LAUNCH_SCHED(2);
+    else if (exp_sched == 3) FBL_GEMM_LAUNCH_SCHED(3);
+    else FBL_GEMM_LAUNCH_SCHED(4);
+    FBL_CHECK_LAUNCH();
+    return 0;
+  }
   if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
   else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_RELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_RELU, FBL_AUX_NONE, false);

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* in_, long ld
   }
 }
 
-constexpr int CS_BLOCKS = 128;
+constexpr int CS_BLOCKS = 512;
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* in_, long ld_in, int rows, int cols, float* ws) {
   // block handles a strided set of rows for a 256-wide column slab

@@ -78,7 +78,13 @@ class Engine:
         self.skip_dead_layer = True
         self._ln_ws = L.ln_bwd_ws(self.H, dev)
         self._cs_ws = L.colsum_ws(max(self.H, self.I), dev)
-        self.sk_ws = torch.empty(16 << 20, dtype=F32, device=dev)  # 64 MiB split-K partials
+        self.sk_ws = torch.empty(16 << 20, dtype=F32, device=dev)  # 64 MiB split-K partials (main stream)
+        # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
+        # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
+        self.side = torch.cuda.Stream(device=dev)
+        self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
+        self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
+        self.use_side_stream = True
 
     # ------------------------------------------------------------------ parameter plumbing
     def _build_flat(self):
@@ -218,12 +224,18 @@ class Engine:
             self.Wv = wv
 
     def _adapter_bwd_operands(self, ent):
-        """W^T operands for the adapter backward (trainable, so rebuilt per step, lazily per layer)."""
+        """W^T operands for the adapter backward (trainable, so rebuilt per step, lazily per layer) -- tile-transpose
+        kernel, zero-padded to the 64-multiple K the GEMM needs."""
         if "upT" not in ent:
-            A, Ap = ent["A"], ent["Ap"]
-            upT = self.Pb[ent["name"] + ".up.weight"].t().contiguous()  # [A,H]
-            downT = torch.zeros(self.H, Ap, dtype=BF16, device=self.dev)
-            downT[:, :A] = self.Pb[ent["name"] + ".down.weight"].t()
+            A, Ap, H = ent["A"], ent["Ap"], self.H
+            upT = torch.empty(A, H, dtype=BF16, device=self.dev)  # [A,H] = up.weight[H,A]^T
+            L.transpose_to_bf16(self.Pb[ent["name"] + ".up.weight"], upT)
+            if Ap == A:
+                downT = torch.empty(H, A, dtype=BF16, device=self.dev)  # [H,A] = down.weight[A,H]^T
+                L.transpose_to_bf16(self.Pb[ent["name"] + ".down.weight"], downT)
+            else:  # K of the consuming GEMM must be a multiple of 64: zero-padded columns
+                downT = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
+                downT[:, :A].copy_(self.Pb[ent["name"] + ".down.weight"].t())
             ent["upT"], ent["downT"] = upT, downT
         return ent["upT"], ent["downT"]
 
@@ -521,9 +533,22 @@ class Engine:
         L.gemm(dz, downT, aux=dyb, aux_kind=L.AUX_ADD_BF16, out_bf16=dx)
         sk = max(2, min(16, N // 512))
         nm = ent["name"]
-        L.gemm_tn_acc(dyb, z, self.G[nm + ".up.weight"], self.sk_ws, N=A, splitk=sk)      # dWu[H,A] += dy^T z
-        L.gemm_tn_acc(dz, xin_b, self.G[nm + ".down.weight"], self.sk_ws, M=A, splitk=sk)  # dWd[A,H] += dz^T x
-        L.colsum(dz, self.G[nm + ".down.bias"], self._cs_ws, cols=A)  # up.bias grad = colsum(dy) comes from ln_bwd
+
+        def dw_work(ws, cs_ws):
+            L.gemm_tn_acc(dyb, z, self.G[nm + ".up.weight"], ws, N=A, splitk=sk)      # dWu[H,A] += dy^T z
+            L.gemm_tn_acc(dz, xin_b, self.G[nm + ".down.weight"], ws, M=A, splitk=sk)  # dWd[A,H] += dz^T x
+            L.colsum(dz, self.G[nm + ".down.bias"], cs_ws, cols=A)  # up.bias grad = colsum(dy) comes from ln_bwd
+
+        if self.use_side_stream:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)  # inputs (dyb, z, dz, xin_b) are ready once main reaches this point
+            with torch.cuda.stream(self.side):
+                dw_work(self.side_ws, self.side_cs_ws)
+            for t in (dyb, z, dz, xin_b):
+                t.record_stream(self.side)  # keep the allocator from recycling them before the side stream is done
+            run.side_used = True
+        else:
+            dw_work(self.sk_ws, self._cs_ws)
         return dx
 
     def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
@@ -593,7 +618,18 @@ class Engine:
         B, S, T = run.B, run.S, run.T
         N = B * S
         self.attach_grads()
-        red = self.reducer
+        reducer = self.reducer
+
+        class _Ready:  # a bucket may only leave once the side-stream dW kernels that fill it have finished
+            def ready(_, key):
+                if getattr(run, "side_used", False):
+                    torch.cuda.current_stream().wait_stream(self.side)
+                reducer.ready(key)
+
+            def finish(_):
+                reducer.finish()
+
+        red = _Ready() if reducer is not None else None
         # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
         rows = torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
         R = rows.numel()
@@ -647,6 +683,8 @@ class Engine:
                 dx, _ = self._layer_bwd(run, sv, dx)
             if red:
                 red.ready(f"layer{sv.li}")
+        if getattr(run, "side_used", False):
+            torch.cuda.current_stream().wait_stream(self.side)  # all adapter dW/db are in the flat grad buffer
         # ---- relative-position LayerNorm (receives grads from every layer execution)
         rn = run.rel_norm
         L.ln_bwd(run.dR, rn.t, rn.stats, rn.gamma, dgamma=self.G["deberta.encoder.LayerNorm.weight"],
