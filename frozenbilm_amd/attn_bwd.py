@@ -16,7 +16,9 @@ from . import lib as L
 BF16, F32 = torch.bfloat16, torch.float32
 
 
-def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
+def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
+    """defer_pos=True: skip the position-table GEMMs and return the state `pos_table_grads` needs (the caller runs it
+    off the critical path); otherwise dpqk [span2, 2H] (bf16, [dPQ|dPK]) is filled here."""
     B, S, H, nh, span2 = run.B, run.S, eng.H, eng.nh, eng.span2
     Sp = (S + 63) // 64 * 64
     dev = eng.dev
@@ -58,16 +60,28 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk):
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
                             rcnt=rcnt, lin=lin)
     del dS, dST
-    # position tables: fp32 [span2, 2H] laid out [dPQ | dPK]; head h writes columns h*64 .. h*64+63
-    dpos = torch.zeros(span2, 2 * H, dtype=F32, device=dev)
+    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp)
+    if defer_pos:
+        return state
+    dpos = pos_table_grads(eng, state, getattr(eng, "sk_ws", None))
+    dpqk.copy_(dpos)  # fp32 -> bf16
+    return None
+
+
+def pos_table_grads(eng, st, ws):
+    """dPK[h] = sum_b G1^T[h] . Q^T[h]^T,  dPQ[h] = sum_b G2^T[h] . K^T[h]^T  -> fp32 [span2, 2H] laid out [dPQ | dPK]
+    (head h owns columns h*64 .. h*64+63); per-head split-K GEMMs on the k-blocked G^T."""
+    H, nh, span2 = eng.H, eng.nh, eng.span2
+    rmin, rcnt, B, Sp = st["rmin"], st["rcnt"], st["B"], st["Sp"]
+    G1T, G2T, QT, KT = st["G1T"], st["G2T"], st["QT"], st["KT"]
+    dpos = torch.zeros(span2, 2 * H, dtype=F32, device=eng.dev)
     Kc = B * Sp
     sk = max(2, min(16, Kc // 1024))
     o_pk = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), H + rmin * 2 * H)
     o_pq = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), rmin * 2 * H)
-    ws = getattr(eng, "sk_ws", None)
     kblk = rcnt * 32  # elements between consecutive 32-wide k blocks of G^T
     a1 = torch.as_strided(G1T, (nh, rcnt, 32), (G1T.stride(0), 32, 1))
     a2 = torch.as_strided(G2T, (nh, rcnt, 32), (G2T.stride(0), 32, 1))
     L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
     L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
-    dpqk.copy_(dpos)  # fp32 -> bf16 into the (strided) tail rows of dqkv
+    return dpos

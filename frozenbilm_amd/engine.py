@@ -282,7 +282,8 @@ class Engine:
         use_ans = bool(m.n_ans) and not mlm
         logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden)
         Vout = self.n_ans if use_ans else self.V
-        res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None}
+        res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None,
+               "logits_event": getattr(run, "logits_event", None)}
         if want_hidden:
             res["hidden_states"] = run.hidden_out
         if full_labels is not None:
@@ -459,10 +460,39 @@ class Engine:
         else:
             Vout, table, bias = self.V, self.Eb, self.head_bias
         ldv = _ru(Vout, 64)
+        run.Vout = Vout
+        loss_t = None
+        if run.labels is not None and run.save and self.use_side_stream:
+            # Training: the loss only needs the labelled rows.  Their logits are computed first (tiny GEMM) so CE and the
+            # whole backward can start, while the full [N, V] logits tensor -- an OUTPUT of the reference API that no
+            # training caller reads -- is produced concurrently on the side stream (MaskedLMOutput waits on access).
+            rows = torch.nonzero(run.labels != -100).view(-1)
+            run.rows_i32 = rows.to(torch.int32)
+            R = rows.numel()
+            run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
+            if R > 0:
+                hrows = torch.empty(R, H, dtype=BF16, device=dev)
+                L.gather_rows_bf16(hl.bf16, run.rows_i32, hrows)
+                lc = torch.empty(R, ldv, dtype=F32, device=dev)
+                L.gemm(hrows, table, bias=bias, out_f32=lc, N=Vout)
+                run.labels_c = run.labels[rows].contiguous()
+                run.row_lse = torch.empty(R, dtype=F32, device=dev)
+                L.ce_fwd(lc, run.labels_c, Vout, run.row_lse, run.loss_acc)
+                run.logits_c = lc
+            loss_t = run.loss_acc[0] / run.loss_acc[1]
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                logits = torch.empty(N, ldv, dtype=F32, device=dev)
+                L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
+                run.logits_event = torch.cuda.Event()
+                run.logits_event.record(self.side)
+            hl.bf16.record_stream(self.side)
+            run.side_used = True
+            run.logits = logits
+            return logits, loss_t
         logits = torch.empty(N, ldv, dtype=F32, device=dev)
         L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
-        run.logits, run.Vout = logits, Vout
-        loss_t = None
+        run.logits = logits
         if run.labels is not None:
             run.row_lse = torch.empty(N, dtype=F32, device=dev)
             run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
@@ -569,46 +599,62 @@ class Engine:
         da = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dh, W["WiT"], aux=dt2, aux_kind=L.AUX_ADD_F32, out_f32=da)
         del dh
-        dt1, dy1, dt1x = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
-                                      dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None,
-                                      tail=self.span2)
+        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
+                                dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None)
         do = dy1
         if "a1" in ad:
             do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
         dctx = torch.empty(N, H, dtype=BF16, device=dev)
         L.gemm(do, W["WoT"], out_bf16=dctx)
-        dqkv = self._attn_bwd(run, sv, dctx)  # [N + P, 3H]: rows N.. hold [dPQ | dPK | 0]
-        # dX = dQKV . Wqkv.  The P tail rows give this execution's dR = [dPQ|dPK].[Wq;Wk] in the same GEMM; it goes
-        # back through pos_dropout and is accumulated over all layer executions.
-        P_ = self.span2
-
-        def take_dr(tail):
-            if run.p_hid > 0:
-                L.dropout_f32(tail, run.p_hid, sv.seed_pos, out_f32=tail)
-            run.dR.add_(tail)
-
+        dqkv, pst = self._attn_bwd(run, sv, dctx)
+        # position tables (off the critical path, side stream): dR += dropout_bwd([dPQ|dPK] . [Wq;Wk]), accumulated over
+        # all layer executions; only encoder.LayerNorm's gamma/beta consume it, at the very end of backward
+        self._pos_grad_async(run, sv, pst, W)
         if not sv.emd:
-            dx = torch.empty(N + P_, H, dtype=F32, device=dev)
-            L.gemm(dqkv, W["WqkvT"], aux=dt1x, aux_kind=L.AUX_ADD_F32, out_f32=dx)
-            take_dr(dx[N:])
-            return dx[:N], None
-        dq = torch.empty(N + P_, H, dtype=F32, device=dev)
-        L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1x, aux_kind=L.AUX_ADD_F32, out_f32=dq)
-        take_dr(dq[N:])
-        dkv = torch.empty(N + P_, H, dtype=F32, device=dev)
+            dx = torch.empty(N, H, dtype=F32, device=dev)
+            L.gemm(dqkv, W["WqkvT"], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dx)
+            return dx, None
+        dq = torch.empty(N, H, dtype=F32, device=dev)
+        L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dq)
+        dkv = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dqkv[:, H:], W["WqkvT"][:, H:], out_f32=dkv)
-        take_dr(dkv[N:])
-        return dq[:N], dkv[:N]
+        return dq, dkv
+
+    def _pos_grad_async(self, run, sv, pst, W):
+        from .attn_bwd import pos_table_grads
+
+        H = self.H
+
+        def work(ws):
+            dpos = pos_table_grads(self, pst, ws)
+            dpb = torch.empty(self.span2, 2 * H, dtype=BF16, device=self.dev)
+            L.cast_bf16(dpos, dpb)
+            if run.p_hid > 0:
+                tmp = torch.empty(self.span2, H, dtype=F32, device=self.dev)
+                L.gemm(dpb, W["WqkvT"][:, : 2 * H], out_f32=tmp)
+                L.dropout_f32(tmp, run.p_hid, sv.seed_pos, out_f32=tmp)
+                run.dR.add_(tmp)
+            else:
+                L.gemm(dpb, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
+
+        if self.use_side_stream:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                work(self.side_ws)
+            for k in ("G1T", "G2T", "QT", "KT"):
+                pst[k].record_stream(self.side)
+            run.side_used = True
+        else:
+            work(self.sk_ws)
 
     def _attn_bwd(self, run, sv, dctx):
         B, S, H, nh = run.B, run.S, self.H, self.nh
         N = B * S
-        dqkv = torch.empty(N + self.span2, 3 * H, dtype=BF16, device=self.dev)
+        dqkv = torch.empty(N, 3 * H, dtype=BF16, device=self.dev)
         from .attn_bwd import disent_attn_bwd
 
-        disent_attn_bwd(self, run, sv, dctx, dqkv[:N], dqkv[N:, : 2 * H])
-        dqkv[N:, 2 * H:].zero_()
-        return dqkv
+        pst = disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True)
+        return dqkv, pst
 
     def backward(self, run, gloss: torch.Tensor):
         """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views)."""
@@ -631,14 +677,19 @@ class Engine:
 
         red = _Ready() if reducer is not None else None
         # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
-        rows = torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
+        compact = getattr(run, "logits_c", None) is not None or getattr(run, "rows_i32", None) is not None
+        rows = run.rows_i32 if compact else torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
         R = rows.numel()
         dq = torch.zeros(N, H, dtype=F32, device=dev)
         if R > 0:
             Vout = run.Vout
             Vp = _ru(Vout, 64)
             dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
-            L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+            if compact:  # logits of the labelled rows only (training path)
+                ar = torch.arange(R, dtype=torch.int32, device=dev)
+                L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+            else:
+                L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
             if Vout == self.V:
                 tableT = self.ETb
             else:

@@ -27,7 +27,21 @@ from .config import DebertaV2Config
 
 
 class MaskedLMOutput(dict):
-    """Attribute + item access (`out.loss`, `out["loss"]`), like transformers' MaskedLMOutput (main.py:67)."""
+    """Attribute + item access (`out.loss`, `out["loss"]`), like transformers' MaskedLMOutput (main.py:67).
+
+    In training the full ``logits`` tensor is produced on a side HIP stream while backward already runs (the loss only
+    needs the labelled rows); the first access makes the current stream wait for it."""
+
+    _logits_event = None
+
+    def _sync_logits(self):
+        ev = self.__dict__.get("_logits_event")
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            lg = super().__getitem__("logits")
+            if lg is not None:
+                lg.record_stream(torch.cuda.current_stream())
+            self.__dict__["_logits_event"] = None
 
     def __getattr__(self, k):
         try:
@@ -37,7 +51,10 @@ class MaskedLMOutput(dict):
 
     def __getitem__(self, k):
         if isinstance(k, int):
+            self._sync_logits()
             return [v for v in self.values() if v is not None][k]
+        if k == "logits":
+            self._sync_logits()
         return super().__getitem__(k)
 
 
@@ -285,6 +302,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states)
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
                              attentions=None)
+        out.__dict__["_logits_event"] = res.get("logits_event")
         if return_dict is False:
             return tuple(v for v in (out["loss"], out["logits"], out["hidden_states"]) if v is not None)
         return out
