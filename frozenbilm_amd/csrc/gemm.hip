@@ -439,8 +439,43 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.Nw = Nw;
   g.a_kblk = a_kblock_stride;
   // big tiles only where both dimensions fill them and the grid still covers the chip
-  const bool big = !accumulate && batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
-  const int BT = big ? 256 : 128;
+  static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
+  const bool big = !force_small && !accumulate && batch == 1 && M >= 2048 && N >= 1024 &&
+                   ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
+  if (big && splitk_ws_floats >= 0) {  // (negative values mark the two halves of an already split launch)
+    // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
+    // round would be mostly empty, give the big tiles only as many M rows as fill whole rounds and run the remaining
+    // rows with the 128x128 configuration (2 workgroups/CU, 1/4 of the work per tile) right behind.
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const int tn = (N + 255) / 256, tm = (M + 255) / 256;
+    const long total = (long)tn * tm;
+    const long rem = total % n_cu;
+    if (total > n_cu && rem != 0 && rem * 3 < (long)n_cu * 2) {  // last round less than 2/3 full
+      const int tm_big = (int)((total - rem) / tn);             // whole rounds worth of M tiles
+      const int m_big = tm_big * 256;
+      if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
+        int rc = fbl_gemm_bf16_nt(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
+                                  out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, stream);
+        if (rc) return rc;
+        const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
+        return fbl_gemm_bf16_nt((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
+                                rowscale ? rowscale + m_big : nullptr, alpha, act, aux_kind,
+                                aux ? (const char*)aux + (size_t)m_big * ld_aux * aux_es : nullptr, ld_aux,
+                                out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
+                                out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
+                                out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
+                                1, nullptr, -2, a_kblock_stride, stream);
+      }
+    }
+  }
+  const bool use_big = big && splitk_ws_floats != -2;  // -2: remainder rows of a split launch -> 128x128 tiles
+  const int BT = use_big ? 256 : 128;
   g.tiles_m = (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
@@ -458,7 +493,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   } while (0)
 #define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                         \
   do {                                                           \
-    if (big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false);           \
+    if (use_big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false);       \
     else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_);                 \
   } while (0)
 #define FBL_GEMM_LAUNCH_SCHED(SCHED_)                                                                          \
@@ -474,7 +509,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     hipLaunchKernelGGL(kfn, grid, dim3(512), smem_bytes, (hipStream_t)stream, g);                              \
   } while (0)
   static const int exp_sched = getenv("FBL_GEMM_SCHED") ? atoi(getenv("FBL_GEMM_SCHED")) : 0;
-  if (big && exp_sched > 0 && act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) {  // experiment switch (plain epilogue)
+  if (use_big && exp_sched > 0 && act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) {  // experiment switch (plain epilogue)
     if (exp_sched == 1) FBL_GEMM_LAUNCH_SCHED(1);
     else if (exp_sched == 2) FBL_GEMM_LAUNCH_SCHED(2);
     else if (exp_sched == 3) FBL_GEMM_LAUNCH_SCHED(3);
