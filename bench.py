@@ -97,7 +97,8 @@ def main():
     model.train(not args.eval_forward)
     eng = model.engine()
     opt = FusedAdam(model, lr=3e-5, betas=(0.9, 0.95))
-    red = GradReducer.attach(model) if world > 1 else None
+    # FBL_FORCE_REDUCER=1 exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
+    red = GradReducer.attach(model) if (world > 1 or os.environ.get("FBL_FORCE_REDUCER")) else None
     B, T, F, Lt = args.batch, 10, 1024, args.text_len
     batch = synth_batch(B, T, F, Lt, cfg.vocab_size, seed=1 + rank, device=dev)
     t_build = time.time() - t_build
