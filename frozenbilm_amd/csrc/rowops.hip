@@ -365,20 +365,59 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* ws, int n
   if ((threadIdx.x >> 4) == 0 && c < cols) out[c] += s;
 }
 
-// Vt[b,h,d,s] = V[b*S+s, h*64+d]; one block per (s-tile of 64, h, b)
+// Vt[b,h,d,s] = V[b*S+s, h*64+d]; one block per (s-tile of 64, h, b).  16-byte global loads and stores: a thread
+// loads two 8-element row chunks, the tile sits in LDS with a 33-dword row stride (conflict-free column walks), and a
+// thread stores 8 consecutive s of one d, 8 lanes covering a full 128-byte output row segment.
 __global__ __launch_bounds__(256) void head_transpose_kernel(const bf16* v, long ldv, bf16* vt, int B, int S, int Sp,
                                                              int nh, long sh, long sb, long sd) {
-  __shared__ bf16 tile[64][66];
+  __shared__ uint32_t tile[64 * 33];
   const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int s = s0 + i;
-    tile[i][tx] = (s < S) ? v[((long)b * S + s) * ldv + h * 64 + tx] : f2bf(0.f);
+  const int t = threadIdx.x;
+  {
+    const int row = t >> 2, c0 = (t & 3) * 2;
+    const int s = s0 + row;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (s < S) x = *(const uint4*)(v + ((long)b * S + s) * ldv + h * 64 + (c0 + c) * 8);
+      uint32_t* d = tile + row * 33 + (c0 + c) * 4;
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
   }
   __syncthreads();
-  for (int d = ty; d < 64; d += 4) {
-    const int s = s0 + tx;
-    if (s < Sp) vt[h * sh + b * sb + d * sd + s] = tile[tx][d];
+  const uint16_t* t16 = (const uint16_t*)tile;
+  const int sc = t & 7;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int d = (t >> 3) + pass * 32;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t lo = t16[(sc * 8 + 2 * k) * 66 + d], hi = t16[(sc * 8 + 2 * k + 1) * 66 + d];
+      w[k] = lo | (hi << 16);
+    }
+    const int s = s0 + sc * 8;
+    if (s < Sp) *(uint4*)(vt + h * sh + b * sb + d * sd + s) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// Batched [rows, cols] -> [cols, rows] bf16 transposes of equally-shaped matrices living at element offsets
+// src_off[z] / dst_off[z] of two base buffers (the adapters' trainable weights inside the flat bf16 parameter copy).
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16* src, const int64_t* src_off, bf16* dst,
+                                                                const int64_t* dst_off, int rows, int cols) {
+  __shared__ bf16 tile[64][66];
+  const bf16* in = src + src_off[blockIdx.z];
+  bf16* out = dst + dst_off[blockIdx.z];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(long)r * cols + c] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(long)c * rows + r] = tile[tx][i];
   }
 }
 
@@ -619,6 +658,15 @@ extern "C" int fbl_transpose_to_bf16(const void* in, int in_is_bf16, int64_t ld_
   return 0;
 }
 
+extern "C" int fbl_transpose_batched_bf16(const void* src_bf16, const int64_t* src_off, void* dst_bf16,
+                                          const int64_t* dst_off, int count, int rows, int cols, void* stream) {
+  if (count <= 0 || rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((rows + 63) / 64, (cols + 63) / 64, count), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16*)src_bf16, src_off, (bf16*)dst_bf16, dst_off, rows, cols);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int64_t fbl_colsum_ws_floats(int cols) { return (int64_t)CS_BLOCKS * cols; }
 extern "C" int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, float* out, float* ws,
                           void* stream) {
@@ -639,6 +687,7 @@ extern "C" int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int row
 extern "C" int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, int S, int Sp, int nh,
                                   int64_t out_sh, int64_t out_sb, int64_t out_sd, void* stream) {
   if (Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if (ldv % 8 || out_sh % 8 || out_sb % 8 || out_sd % 8 || ((uintptr_t)v_bf16 & 15) || ((uintptr_t)vt_bf16 & 15)) return FBL_ERR_ALIGN;
   if (B * S <= 0) return 0;
   hipLaunchKernelGGL(head_transpose_kernel, dim3(Sp / 64, nh, B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)v_bf16, (long)ldv, (bf16*)vt_bf16, B, S, Sp, nh, (long)out_sh, (long)out_sb,

@@ -103,6 +103,7 @@ class Engine:
         self.flat_grad = torch.zeros(total, dtype=F32, device=self.dev)
         self.flat_bf16 = torch.zeros(total, dtype=BF16, device=self.dev)
         self.offsets, self.order = offs, order
+        self._adT_offs = {}
         self.G: Dict[str, torch.Tensor] = {}
         self.Pb: Dict[str, torch.Tensor] = {}
         for n in order:
@@ -224,19 +225,38 @@ class Engine:
             self.Wv = wv
 
     def _adapter_bwd_operands(self, ent):
-        """W^T operands for the adapter backward (trainable, so rebuilt per step, lazily per layer) -- tile-transpose
-        kernel, zero-padded to the 64-multiple K the GEMM needs."""
+        """W^T operands for the adapter backward (trainable, so rebuilt after every optimizer step): all adapters of a
+        shape are transposed by ONE batched launch straight out of the flat bf16 parameter copy, on first use in a
+        step.  Bottlenecks that are not a multiple of 64 take the zero-padded per-adapter path."""
         if "upT" not in ent:
-            A, Ap, H = ent["A"], ent["Ap"], self.H
-            upT = torch.empty(A, H, dtype=BF16, device=self.dev)  # [A,H] = up.weight[H,A]^T
-            L.transpose_to_bf16(self.Pb[ent["name"] + ".up.weight"], upT)
-            if Ap == A:
-                downT = torch.empty(H, A, dtype=BF16, device=self.dev)  # [H,A] = down.weight[A,H]^T
-                L.transpose_to_bf16(self.Pb[ent["name"] + ".down.weight"], downT)
-            else:  # K of the consuming GEMM must be a multiple of 64: zero-padded columns
-                downT = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
-                downT[:, :A].copy_(self.Pb[ent["name"] + ".down.weight"].t())
-            ent["upT"], ent["downT"] = upT, downT
+            H = self.H
+            groups = {}
+            for e in self.ad:
+                for key in ("a1", "a2"):
+                    if key in e:
+                        groups.setdefault((e[key]["A"], e[key]["Ap"]), []).append(e[key])
+            for (A, Ap), ents in groups.items():
+                upT_all = torch.empty(len(ents), A, H, dtype=BF16, device=self.dev)
+                for i, e in enumerate(ents):
+                    e["upT"] = upT_all[i]  # [A,H] = up.weight[H,A]^T
+                cache = self._adT_offs.get((A, Ap))
+                if cache is None:
+                    i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=self.dev)
+                    cache = dict(up_src=i64([self.offsets[e["name"] + ".up.weight"] for e in ents]),
+                                 dn_src=i64([self.offsets[e["name"] + ".down.weight"] for e in ents]),
+                                 dst=i64([i * A * H for i in range(len(ents))]))
+                    self._adT_offs[(A, Ap)] = cache
+                L.transpose_batched_bf16(self.flat_bf16, cache["up_src"], upT_all, cache["dst"], H, A)
+                if Ap == A:
+                    dnT_all = torch.empty(len(ents), H, A, dtype=BF16, device=self.dev)
+                    L.transpose_batched_bf16(self.flat_bf16, cache["dn_src"], dnT_all, cache["dst"], A, H)
+                    for i, e in enumerate(ents):
+                        e["downT"] = dnT_all[i]  # [H,A] = down.weight[A,H]^T
+                else:  # K of the consuming GEMM must be a multiple of 64: zero-padded columns
+                    for e in ents:
+                        downT = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
+                        downT[:, :A].copy_(self.Pb[e["name"] + ".down.weight"].t())
+                        e["downT"] = downT
         return ent["upT"], ent["downT"]
 
     # ------------------------------------------------------------------ public entry

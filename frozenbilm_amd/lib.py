@@ -36,6 +36,7 @@ SIGNATURES = {
     "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dropout_gelu_bwd": (_i, [_vp, _vp, _f, _u64, _vp, _vp, _l, _vp]),
     "fbl_transpose_to_bf16": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp]),
+    "fbl_transpose_batched_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fbl_colsum_ws_floats": (_l, [_i]),
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
@@ -236,6 +237,14 @@ def dropout_gelu_fwd(c, p_drop, seed, out_f32):
 def dropout_gelu_bwd(dy, c, p_drop, seed, out_bf16=None, out_f32=None):
     _chk(load().fbl_dropout_gelu_bwd(_p(dy), _p(c), float(p_drop), int(seed), _p(out_bf16), _p(out_f32), c.numel(),
                                      _stream()), "fbl_dropout_gelu_bwd")
+
+
+def transpose_batched_bf16(src, src_off, dst, dst_off, rows, cols):
+    """dst[dst_off[i]:][cols, rows] = src[src_off[i]:][rows, cols]^T for every i; offsets: int64 device tensors (elements)."""
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16
+    assert src_off.dtype == torch.int64 and dst_off.dtype == torch.int64 and src_off.numel() == dst_off.numel()
+    _chk(load().fbl_transpose_batched_bf16(_p(src), _p(src_off), _p(dst), _p(dst_off), src_off.numel(), rows, cols,
+                                           _stream()), "fbl_transpose_batched_bf16")
 
 
 def transpose_to_bf16(x, out, rows=None, cols=None):

@@ -112,6 +112,12 @@ int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t
 int fbl_transpose_to_bf16(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, void* out_bf16,
                           int64_t rows_pad, void* stream);
 
+/* count equally-shaped contiguous bf16 matrices [rows, cols] at element offsets src_off[i] of src are written
+ * transposed ([cols, rows]) at dst_off[i] of dst; offsets are int64 arrays in device memory.  One launch rebuilds the
+ * W^T operands of all adapters (autograd of model/adapter.py:38,42) after an optimizer step. */
+int fbl_transpose_batched_bf16(const void* src_bf16, const int64_t* src_off, void* dst_bf16, const int64_t* dst_off,
+                               int count, int rows, int cols, void* stream);
+
 /* out[c] += sum_r in[r, c]  (bias gradients).  in fp32 or bf16.  ws: fbl_colsum_ws_floats(cols) floats. */
 int64_t fbl_colsum_ws_floats(int cols);
 int fbl_colsum(const void* in, int in_is_bf16, int64_t ld_in, int rows, int cols, float* out, float* ws,

@@ -324,6 +324,25 @@ def test_transpose_colsum(L):
     assert torch.equal(acc[100:], acc0[100:])
 
 
+def test_transpose_batched(L):
+    rows, cols, cnt = 192, 1536, 5
+    flat = rnd(7 + cnt * (rows * cols + 24), seed=3).to(BF16)
+    src_off = torch.tensor([8 + i * (rows * cols + 24) for i in range(cnt)], dtype=torch.int64, device=DEV)
+    dst = torch.zeros(cnt, cols, rows, dtype=BF16, device=DEV)
+    dst_off = torch.tensor([i * rows * cols for i in range(cnt)], dtype=torch.int64, device=DEV)
+    L.transpose_batched_bf16(flat, src_off, dst, dst_off, rows, cols)
+    for i in range(cnt):
+        o = int(src_off[i])
+        assert torch.equal(dst[i], flat[o:o + rows * cols].view(rows, cols).t())
+    # ragged shape (not a multiple of the 64x64 tile)
+    rows, cols = 70, 33
+    flat = rnd(2 * rows * cols, seed=4).to(BF16)
+    off = torch.tensor([0, rows * cols], dtype=torch.int64, device=DEV)
+    dst = torch.zeros(2, cols, rows, dtype=BF16, device=DEV)
+    L.transpose_batched_bf16(flat, off, dst, off, rows, cols)
+    assert torch.equal(dst[1], flat[rows * cols:].view(rows, cols).t())
+
+
 def test_head_transpose(L):
     B, S, nh = 2, 70, 3
     Sp = 128
