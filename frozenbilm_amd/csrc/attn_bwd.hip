@@ -69,7 +69,7 @@ static_assert(64 * LT * 2 >= 64 * LDV * 2, "dS staging tile must fit in the T1 r
 
 struct ATileRegs {
   bf16x8 q[2], d[2], pk[4], pq[4];
-  float lse, D, qv;
+  float lse, D;
 };
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
@@ -81,18 +81,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   const int S = a.S, Sp = a.Sp;
   const int j = j0 + w * 16 + c;  // this lane's key
   const int jc = min(j, S - 1);
-  const int hi = 2 * S - 2;
+  const int tq = Sp - 1;  // idx[i - j + tq]
 
   int16_t* idx = (int16_t*)(smem + A_IDX);
   f16* T1 = (f16*)(smem + A_T1);
   f16* T2w = (f16*)(smem + A_T2) + w * 16 * LT;
   float* rlse = (float*)(smem + A_ROW);
   float* rD = rlse + 64;
-  float* rqv = rD + 64;
   bf16* dst = (bf16*)(smem + A_T1);   // dS tile [query][key] after the gather
   bf16* dstT = (bf16*)(smem + A_T2);  // dS^T tile [key][query]
 
-  for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
+  load_idx_padded(idx, a.relidx, S, Sp, tid, 256);
 
   bf16x8 kf[2], vf[2];
   {
@@ -102,13 +101,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
     vf[0] = *(const bf16x8*)(a.v + off);
     vf[1] = *(const bf16x8*)(a.v + off + 32);
   }
-  const float kvalid = (j < S && a.mask[(long)b * S + jc] != 0) ? 1.f : 0.f;
+  const bool kvalid = j < S && a.mask[(long)b * S + jc] != 0;
 
   f32x4 dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const uint32_t thr = fbl_drop_thresh(a.p_drop);
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
+  const float k2 = a.scale * LOG2E;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
   const bf16* dOTh = a.dOT + h * a.t_sh + b * a.t_sb;
   const int kl = a.klen ? min(a.klen[b], S) : S;
@@ -124,20 +123,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       R.q[t] = *(const bf16x8*)(a.q + ((long)b * S + i) * a.ldq + h * 64 + sch * 8);
       R.d[t] = *(const bf16x8*)(a.dO + ((long)b * S + i) * a.ldo + h * 64 + sch * 8);
     }
-    R.lse = INFINITY; R.D = 0.f; R.qv = 0.f;
+    R.lse = INFINITY; R.D = 0.f;  // lse = +inf (padding and masked queries: the forward stores +inf) -> P = 0
     if (tid < 64) {
       const int i = i0 + tid;
       if (i < S) {
         const long o = ((long)b * a.nh + h) * S + i;
-        R.lse = a.lse[o];
+        R.lse = a.lse[o] * LOG2E;
         R.D = a.Dv[o];
-        R.qv = a.mask[(long)b * S + i] != 0 ? 1.f : 0.f;
       }
     }
   };
   auto load_win = [&](int it, ATileRegs& R) {  // issued late in the iteration: keeps 32 VGPRs free during the gather
     const int i0 = it * 64;
-    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    const int r_lo = idx[i0 - (j0 + 63) + tq];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = min(r_lo + srow + t * 32, a.span2 - 1);
@@ -160,7 +158,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
     if (tid < 64) {
       rlse[tid] = R.lse;
       rD[tid] = R.D;
-      rqv[tid] = R.qv;
     }
   };
 
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   }
   for (int it = 0; it < nqt; ++it) {
     const int i0 = it * 64;
-    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    const int r_lo = idx[i0 - (j0 + 63) + tq];
     store_tile(R);
     __syncthreads();
     if (it + 1 < nqt) load_qd(it + 1, R);
@@ -181,11 +178,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) dts[t] = *(const bf16x8*)(dOTh + (long)(srow + t * 32) * a.t_sd + i0 + sch * 8);
     // sub-window offsets: this wave's 16 keys (T2) and each 16-query tile (T1)
-    const int off2 = idx[clampi(i0 - (j0 + w * 16 + 15) + S - 1, 0, hi)] - r_lo;
-    int off1[4];
+    const int base2 = idx[i0 - (j0 + w * 16 + 15) + tq];  // absolute table row of T2w[.][0]
+    const int off2 = base2 - r_lo;
+    int base1[4];                                          // absolute table row of T1[query tile nt][.][0]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) off1[nt] = idx[clampi(i0 + nt * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
-    const int off1w = idx[clampi(i0 + w * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
+    for (int nt = 0; nt < 4; ++nt) base1[nt] = idx[i0 + nt * 16 - (j0 + 63) + tq];
+    const int off1w = idx[i0 + w * 16 - (j0 + 63) + tq] - r_lo;
 
     // ---- (1) scores: sacc[nt][r] = Q_i . K_j,  i = i0 + nt*16 + g*4 + r, key column c
     f32x4 sacc[4];
@@ -197,22 +195,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       sacc[nt] = acc;
     }
     // ---- (2) T2 for this wave's keys (private), T1 for query tile w (shared)
-    bias_tile(smem + A_PQ, off2, kf[0], kf[1], T2w + c * LT, c, g);
+    bias_tile(smem + A_PQ, off2, kf[0], kf[1], T2w + c * LT, c, g, kvalid);  // masked key: T2 row = -inf -> P = 0
     bias_tile(smem + A_PK, off1w, lds_frag(smem + A_QS, w * 16 + c, g), lds_frag(smem + A_QS, w * 16 + c, 4 + g),
               T1 + (w * 16 + c) * LT, c, g);
     __syncthreads();
 
-    // ---- (3) P (same arithmetic as the forward)
+    // ---- (3) P (same arithmetic as the forward).  The window offsets are clamped here (one v_med3 each): padding
+    // queries must give an exact P = 0 (finite score, lse = +inf), not garbage, because their dS rows are stored.
     float p[16];
+    {
+      const int16_t* ib = idx + (i0 + g * 4 - j + tq);
+      const f16* t1g = T1 + g * 4 * LT;
+      const f16* t2row = T2w + c * LT;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int il = nt * 16 + g * 4 + r;
-        const int wi = (int)idx[clampi(i0 + il - j + S - 1, 0, hi)] - r_lo;
-        const int w1 = clampi(wi - off1[nt], 0, 79), w2 = clampi(wi - off2, 0, 79);
-        const float s = (sacc[nt][r] + (float)T1[il * LT + w1] + (float)T2w[c * LT + w2]) * a.scale;
-        p[nt * 4 + r] = (kvalid * rqv[il] != 0.f) ? __expf(s - rlse[il]) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const int wi = ib[nt * 16 + r];
+          const int w1 = clampi(wi - base1[nt], 0, 79), w2 = clampi(wi - base2, 0, 79);
+          const float s = sacc[nt][r] + (float)t1g[(nt * 16 + r) * LT + w1] + (float)t2row[w2];
+          p[nt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s, k2, -rlse[nt * 16 + g * 4 + r]));
+        }
       }
     }
     if (it + 1 < nqt) load_win(it + 1, R);
@@ -225,16 +228,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, g), vf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, 4 + g), vf[1], acc, 0, 0, 0);
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          uint32_t x, y;
+          attn_drop_block(dk, (i0 + nt * 16 + g * 4 + bb * 2) >> 1, j >> 1, Sp >> 1, &x, &y);
+          keep[bb * 2] = attn_drop_keep(dk, x, y, 0, j & 1);
+          keep[bb * 2 + 1] = attn_drop_keep(dk, x, y, 1, j & 1);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = nt * 16 + g * 4 + r;
-        float keep = 1.f;
-        if (a.p_drop > 0.f)
-          keep = fbl_dropout_scale(a.seed, (((uint64_t)b * a.nh + h) * S + (uint64_t)min(i0 + il, S - 1)) * S + (uint64_t)jc,
-                                   thr, inv_keep);
         const float pv = p[nt * 4 + r];
-        dsb[nt][r] = f2bf(pv * (acc[r] * keep - rD[il]) * a.scale);
-        pfh[nt][r] = f2bf(pv * keep);
+        dsb[nt][r] = f2bf(pv * (acc[r] * keep[r] - rD[il]) * a.scale);
+        pfh[nt][r] = f2bf(pv * keep[r]);
       }
     }
     __syncthreads();  // dO^T tile visible; every wave is done gathering from T1 / T2 (reused below as dS staging)

@@ -25,24 +25,72 @@ __device__ __forceinline__ void lds_put(char* base, int row, int chunk, bf16x8 v
   *(bf16x8*)(base + row * 128 + ((chunk ^ (row & 7)) << 4)) = v;
 }
 __device__ __forceinline__ f16x4 to_f16x4(f32x4 v) {
-  f16x4 o;
+  f32x4 m;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (f16)fminf(fmaxf(v[e], -65504.f), 65504.f);
-  return o;
+  for (int e = 0; e < 4; ++e) m[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+  return __builtin_convertvector(m, f16x4);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Relative-index table padded to the 64-tile grid: idxp[t] = relidx[clamp(t - (Sp - S), 0, 2S-2)] with t = i - j + Sp - 1,
+// so that every (i, j) of a tile (valid or padding) indexes it without a clamp.  2*Sp - 1 <= 1023 entries.
+__device__ __forceinline__ void load_idx_padded(int16_t* idxp, const int16_t* relidx, int S, int Sp, int tid, int nthr) {
+  for (int t = tid; t < 2 * Sp - 1; t += nthr) idxp[t] = relidx[clampi(t - (Sp - S), 0, 2 * S - 2)];
+}
+
 // T[col c][sub-window] = X_c . TAB[off + .]   for the 16 columns held as B-fragments xb0/xb1 (k-steps of d);
 // tab: swizzled [128][64] bf16 LDS image of the table window; dst: fp16 tile, row stride LT, this lane's row = c.
-__device__ __forceinline__ void bias_tile(const char* tab, int off, bf16x8 xb0, bf16x8 xb1, f16* dst_row_c, int c, int g) {
+// colvalid = false writes -inf for the whole row (a masked key: its score becomes -inf without a per-element test).
+__device__ __forceinline__ void bias_tile(const char* tab, int off, bf16x8 xb0, bf16x8 xb1, f16* dst_row_c, int c, int g,
+                                          bool colvalid = true) {
+  const f16 ninf = (f16)(-INFINITY);
 #pragma unroll
   for (int wt = 0; wt < TW; ++wt) {
     const int row = min(off + wt * 16 + c, 127);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(tab, row, g), xb0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(tab, row, 4 + g), xb1, acc, 0, 0, 0);
-    *(f16x4*)(dst_row_c + wt * 16 + g * 4) = to_f16x4(acc);
+    const f16x4 t = to_f16x4(acc);
+    *(f16x4*)(dst_row_c + wt * 16 + g * 4) = colvalid ? t : (f16x4){ninf, ninf, ninf, ninf};
   }
+}
+
+// ---- attention-probability dropout RNG (shared by the forward and the backward-A kernels).
+// One 32-bit counter hash serves a 2x2 block of (query, key) pairs: four 16-bit fields, field (i&1)*2 + (j&1), each
+// compared with a 16-bit threshold (p quantised to 1/65536; the kept values are scaled by the exact 1/(1-p_q)).
+// 32-bit integer multiplies are quarter rate on CDNA, so this costs ~6x fewer issue slots than one 64-bit mix per
+// element.  Keys are derived per (seed, batch*head) with the common 64-bit mixer.
+struct DropKey {
+  uint32_t k1, k2, thr16;
+  float inv_keep;
+};
+__device__ __forceinline__ DropKey attn_drop_key(uint64_t seed, int bh, float p) {
+  DropKey k;
+  k.k1 = fbl_hash(seed, 2ull * (uint64_t)bh);
+  k.k2 = fbl_hash(seed, 2ull * (uint64_t)bh + 1ull);
+  const float t = p * 65536.f + 0.5f;
+  k.thr16 = p > 0.f ? (uint32_t)fminf(t, 65535.f) : 0u;
+  k.inv_keep = 65536.f / (65536.f - (float)k.thr16);
+  return k;
+}
+// the two words of block (bi, bj) = (i >> 1, j >> 1); Sp2 = Sp / 2
+__device__ __forceinline__ void attn_drop_block(const DropKey& k, int bi, int bj, int Sp2, uint32_t* x_out, uint32_t* y_out) {
+  uint32_t x = (uint32_t)(bi * Sp2 + bj) * 0x9E3779B1u + k.k1;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  uint32_t y = (x ^ k.k2) * 0x2c1b3c6du;
+  y ^= y >> 15;
+  *x_out = x;
+  *y_out = y;
+}
+// keep factor (0 or 1/(1-p)) of the element with parities (pi, pj) inside its block
+__device__ __forceinline__ float attn_drop_keep(const DropKey& k, uint32_t x, uint32_t y, int pi, int pj) {
+  const uint32_t wsel = pi ? y : x;
+  const uint32_t f = pj ? (wsel >> 16) : (wsel & 0xffffu);
+  return f >= k.thr16 ? k.inv_keep : 0.f;
 }
 
 }  // namespace attn

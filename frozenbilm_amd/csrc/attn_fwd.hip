@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int S = a.S;
+  const int S = a.S, Sp = a.Sp;
   const int i = i0 + w * 16 + c;  // this lane's query row
   const int ic = min(i, S - 1);
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   f16* T1w = (f16*)(smem + SM_T1) + w * 16 * LT;
   f16* T2 = (f16*)(smem + SM_T2);
 
-  for (int t = tid; t < 2 * S - 1; t += 256) idx[t] = a.relidx[t];
+  load_idx_padded(idx, a.relidx, S, Sp, tid, 256);
 
   bf16x8 qf[2];
   {
@@ -72,24 +72,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     qf[0] = *(const bf16x8*)qp;
     qf[1] = *(const bf16x8*)(qp + 32);
   }
-  const float qvalid = (i < S && a.mask[(long)b * S + ic] != 0) ? 1.f : 0.f;
+  const bool qvalid = i < S && a.mask[(long)b * S + ic] != 0;
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const uint32_t thr = fbl_drop_thresh(a.p_drop);
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
+  const float k2 = a.scale * LOG2E;  // scores stay unscaled; softmax runs in the exp2 domain
   const int kl = a.klen ? min(a.klen[b], S) : S;
   const int nkt = (i0 < kl) ? (kl + 63) / 64 : 0;  // masked key tiles contribute exactly 0; a fully masked query tile outputs 0
-  const int hi = 2 * S - 2;
+  const int tq = Sp - 1;  // idx[i - j + tq]
   __syncthreads();  // idx table visible
 
   const int srow = tid >> 3, sch = tid & 7;  // staging role of this thread: row (0..31) and 16-byte chunk
   auto load_tile = [&](int jt, TileRegs& R) {
     const int j0 = jt * 64;
-    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    const int r_lo = idx[i0 - (j0 + 63) + tq];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = srow + t * 32;
@@ -130,17 +130,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   if (nkt > 0) load_tile(0, R);
   for (int jt = 0; jt < nkt; ++jt) {
     const int j0 = jt * 64;
-    const int r_lo = idx[clampi(i0 - (j0 + 63) + S - 1, 0, hi)];
+    const int r_lo = idx[i0 - (j0 + 63) + tq];
     store_tile(R);
     __syncthreads();
     if (jt + 1 < nkt) load_tile(jt + 1, R);  // in flight while this tile is computed
 
     // sub-window offsets: this wave's 16 queries (T1) and each 16-key tile (T2)
-    const int off1 = idx[clampi(i0 + w * 16 - (j0 + 63) + S - 1, 0, hi)] - r_lo;
-    int off2[4];
+    const int base1 = idx[i0 + w * 16 - (j0 + 63) + tq];  // absolute table row of T1w[.][0]
+    const int off1 = base1 - r_lo;
+    int base2[4];                                          // absolute table row of T2[key tile nt][.][0]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) off2[nt] = idx[clampi(i0 - (j0 + nt * 16 + 15) + S - 1, 0, hi)] - r_lo;
-    const int off2w = idx[clampi(i0 - (j0 + w * 16 + 15) + S - 1, 0, hi)] - r_lo;
+    for (int nt = 0; nt < 4; ++nt) base2[nt] = idx[i0 - (j0 + nt * 16 + 15) + tq];
+    const int off2w = idx[i0 - (j0 + w * 16 + 15) + tq] - r_lo;
 
     // ---- (1) content scores, transposed: sacc[nt][r] = Q_i . K_j,  j = j0 + nt*16 + g*4 + r
     f32x4 sacc[4];
@@ -154,23 +155,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // ---- (2) T1 for this wave's queries, (3) T2 for key tile w
     bias_tile(smem + SM_PK, off1, qf[0], qf[1], T1w + c * LT, c, g);
     bias_tile(smem + SM_PQ, off2w, lds_frag(smem + SM_KS, w * 16 + c, g), lds_frag(smem + SM_KS, w * 16 + c, 4 + g),
-              T2 + (w * 16 + c) * LT, c, g);
+              T2 + (w * 16 + c) * LT, c, g, kms[w * 16 + c] != 0.f);  // masked keys: whole T2 row = -inf
     __syncthreads();
 
-    // ---- (4) gather the bias terms, mask, online softmax
+    // ---- (4) gather the bias terms, online softmax.  No clamps: in-range (i, j) always land inside the 80-wide
+    // sub-windows; padding queries read finite garbage that stays in their own lane column and is dropped at the end,
+    // padding / masked keys carry -inf through their T2 row.
     float p[16];
     float mx = -INFINITY;
+    {
+      const int16_t* ib = idx + (i - j0 - g * 4 + tq - 63);
+      const f16* t1row = T1w + c * LT - base1;
+      const f16* t2g = T2 + g * 4 * LT;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 4; ++nt) {
+        const f16* t2n = t2g - base2[nt];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jl = nt * 16 + g * 4 + r;
-        const int wi = (int)idx[clampi(i - (j0 + jl) + S - 1, 0, hi)] - r_lo;
-        const int w1 = clampi(wi - off1, 0, 79), w2 = clampi(wi - off2[nt], 0, 79);
-        float s = (sacc[nt][r] + (float)T1w[c * LT + w1] + (float)T2[jl * LT + w2]) * a.scale;
-        s = (kms[jl] * qvalid != 0.f) ? s : -INFINITY;
-        p[nt * 4 + r] = s;
-        mx = fmaxf(mx, s);
+        for (int r = 0; r < 4; ++r) {
+          const int wi = ib[63 - nt * 16 - r];
+          const float s = sacc[nt][r] + (float)t1row[wi] + (float)t2n[(nt * 16 + r) * LT + wi];
+          p[nt * 4 + r] = s;
+          mx = fmaxf(mx, s);
+        }
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -181,10 +187,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = 0.f;
     } else {
-      alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * k2);  // m_run = -inf -> 0
+      const float mk = -m_new * k2;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        p[e] = __expf(p[e] - m_new);
+        p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], k2, mk));
         psum += p[e];
       }
     }
@@ -195,12 +202,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
     if (a.p_drop > 0.f) {
-      const uint64_t rowbase = (((uint64_t)b * a.nh + h) * S + (uint64_t)ic) * S;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          p[nt * 4 + r] *= fbl_dropout_scale(a.seed, rowbase + (uint64_t)(j0 + nt * 16 + g * 4 + r), thr, inv_keep);
+        for (int bb = 0; bb < 2; ++bb) {
+          uint32_t x, y;
+          attn_drop_block(dk, i >> 1, (j0 + nt * 16 + g * 4 + bb * 2) >> 1, Sp >> 1, &x, &y);
+          p[nt * 4 + bb * 2] *= attn_drop_keep(dk, x, y, i & 1, 0);
+          p[nt * 4 + bb * 2 + 1] *= attn_drop_keep(dk, x, y, i & 1, 1);
+        }
     }
     // ---- (5) O^T += V^T . P^T ; k-slot e of step kk  <->  key kk*32 + (e>>2)*16 + g*4 + (e&3)
 #pragma unroll
@@ -228,15 +238,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();  // LDS tiles are overwritten by the next key tile
   }
 
-  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  const float inv_l = (qvalid && l_run > 0.f) ? 1.f / l_run : 0.f;
   if (i < S) {
     bf16* op = a.ctx + ((long)b * S + i) * a.ldo + h * 64 + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const f32x4 v = o[dt] * inv_l;
+      f32x4 v = o[dt] * inv_l;
+      if (inv_l == 0.f) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // masked query rows are exactly zero (their lane may hold garbage)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
     }
-    if (g == 0 && a.lse) a.lse[((long)b * a.nh + h) * S + i] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+    if (g == 0 && a.lse)
+      a.lse[((long)b * a.nh + h) * S + i] = (qvalid && l_run > 0.f) ? m_run * a.scale + __logf(l_run) : INFINITY;
   }
 }
 

@@ -552,3 +552,71 @@ def test_attention_bwd(L, B, S, nh):
     sp = pqkf.grad.abs().max().item()
     close(dpqk[:, H:], pqkf.grad[:, H:], 3e-2, 2e-2 * sp, "dPK")
     close(dpqk[:, :H], pqkf.grad[:, :H], 3e-2, 2e-2 * sp, "dPQ")
+
+
+def _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p_att, seed):
+    from frozenbilm_amd.attn_bwd import disent_attn_bwd
+    import types as _t
+
+    class E:
+        pass
+
+    eng, run, sv = E(), E(), E()
+    eng.H, eng.nh, eng.span2, eng.dev = H, nh, pqk.shape[0], torch.device(DEV)
+    eng.relidx = lambda S_: relidx
+    eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)
+    run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), p_att
+    run.klen = None
+    sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, seed
+    dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
+    dpqk = torch.zeros(pqk.shape[0], 2 * H, dtype=BF16, device=DEV)
+    disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk)
+    return dqkv, dpqk
+
+
+def test_attention_dropout_mask_fwd_bwd_agree(L):
+    """V = I and dO = I expose the dropped-out probability matrix in both directions: forward ctx = drop(P), backward
+    dV = drop(P)^T -- the two kernels must regenerate the SAME mask; its statistics must look like iid Bernoulli(1-p)."""
+    B, S, nh, p = 2, 64, 2, 0.1
+    qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=77)
+    mask[:] = 1
+    qkv = (qkv.float() * 0.3).to(BF16)  # mild scores: every P entry is well above bf16 underflow
+    eye = torch.eye(64, device=DEV).repeat(B, nh).to(BF16)  # V[b*S+s, h*64+d] = (s == d)
+    qkv[:, 2 * H:] = eye
+    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=1234)
+    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, eye.clone(), mask, relidx, B, S, nh, H, p, 1234)
+    Pf = heads(ctx.float(), B, S, nh)                 # [B,nh,S(query),64(key)]
+    Pb = heads(dqkv[:, 2 * H:].float(), B, S, nh)     # [B,nh,S(key),64(query)]
+    assert torch.equal(Pf == 0, Pb.transpose(-1, -2) == 0)
+    close(Pf, Pb.transpose(-1, -2), 2e-2, 1e-4, "drop(P) fwd vs bwd")
+    drop = (Pf == 0).float()
+    n = drop.numel()
+    rate = drop.mean().item()
+    assert abs(rate - p) < 4 * math.sqrt(p * (1 - p) / n), rate
+    d0 = drop - rate
+    for name, a_, b_ in (("key+1", d0[..., :, :-1], d0[..., :, 1:]), ("query+1", d0[..., :-1, :], d0[..., 1:, :]),
+                         ("diag", d0[..., :-1, :-1], d0[..., 1:, 1:])):
+        corr = (a_ * b_).mean().item() / (p * (1 - p))
+        assert abs(corr) < 5 / math.sqrt(a_.numel()), (name, corr)
+    # a different seed gives a different mask; the (batch, head) streams differ from each other
+    ctx2, _ = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=1235)
+    assert not torch.equal(ctx2 == 0, ctx == 0)
+    assert not torch.equal(drop[0, 0], drop[0, 1]) and not torch.equal(drop[0, 0], drop[1, 0])
+
+
+def test_attention_dropout_bwd_linearity(L):
+    """multi-tile, ragged: ctx is linear in V for a fixed mask, so <ctx, dO> == <V, dV> iff backward uses the forward mask."""
+    B, S, nh, p = 2, 150, 2, 0.1
+    qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=78)
+    qkv = (qkv.float() * 0.5).to(BF16)
+    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=99)
+    dctx = bf(rnd(B * S, H, seed=6)).to(BF16)
+    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 99)
+    for h in range(nh):
+        sl = slice(h * 64, (h + 1) * 64)
+        lhs = (ctx[:, sl].float() * dctx[:, sl].float()).sum().item()
+        rhs = (qkv[:, 2 * H:][:, sl].float() * dqkv[:, 2 * H:][:, sl].float()).sum().item()
+        assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), 10.0), (h, lhs, rhs)
+    # wrong seed in backward breaks the identity by far more than the tolerance
+    dq2, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 100)
+    assert (dq2[:, 2 * H:].float() - dqkv[:, 2 * H:].float()).abs().max().item() > 1e-2
