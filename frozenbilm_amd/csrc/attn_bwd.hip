@@ -308,10 +308,18 @@ struct ShearArgs {
   int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
   int lin;                                // |delta| < lin: idx(delta) is injective (identity buckets) -> plain stores
 };
-constexpr int C_YT = 0;                     // [64 d][72] bf16
-constexpr int C_IDX = C_YT + 64 * LDV * 2;  // int16[1024]
-constexpr int C_G = C_IDX + 2048;           // [32][Wg + 4] fp32
+constexpr int C_IDX = 0;           // int16[1024]: relative-index table padded to the tile grid
+constexpr int C_G = C_IDX + 2048;  // [32][Wg + 4] fp32
 
+// 2 waves x 16 rows; after the initial barrier (cooperative zeroing of G, index table) the waves never synchronise:
+//  * the transposed-operand fragments come straight from global memory (L2-resident: every row tile of a (batch, head)
+//    re-reads them) into registers one column tile ahead;
+//  * each wave scatters only into its own 16 rows of G.  A 16x64 patch that lies entirely in the identity-bucket band
+//    (|i-j| < lin, idx = delta + idx(0)) needs no table lookup and no atomics: one unconditional LDS store per element
+//    (zeros of padded / masked positions are diverted to the row's padding slot);
+//  * the table GEMM walks only the index range the valid columns [0, klen) can reach, and G^T leaves through the
+//    matrix cores: D = G_frag . I puts 4 consecutive rows of one table index in a lane (an exact transpose of the bf16
+//    values), so there is no column-wise LDS read-out.
 template <bool NEG>
 __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,93 +333,120 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int row = r0 + rl;
   float* G = (float*)(smem + C_G);
   int16_t* idx = (int16_t*)(smem + C_IDX);
-  {  // rows entirely beyond the sample's last valid position: dS is zero there -> zero output rows, zero G^T block
-    const int kl0 = a.klen ? min(a.klen[b], S) : S;
-    if (r0 >= kl0) {
-      const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
-      for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
-      if (row < S) {
-        bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
+  bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
+  const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
+    for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
+    if (row < S) {
+      bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = (bf16x4){0, 0, 0, 0};
-      }
-      return;
+      for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = (bf16x4){0, 0, 0, 0};
     }
+    return;
   }
-  for (int t = tid; t < 32 * LDG; t += 128) G[t] = 0.f;
-  for (int t = tid; t < 2 * S - 1; t += 128) idx[t] = a.relidx[t];
-  // smallest reachable index for these 32 rows, aligned down to 8 so the PT fragments stay 16-byte aligned
-  const int dlo = NEG ? -(r0 + 31) : r0 - (S - 1);
+  // table rows reachable from these 32 rows x the valid columns [0, kl): [rbase, rtop]; rbase aligned down to 8 so the
+  // PT fragments stay 16-byte aligned.  dS is only defined (and non-zero) inside [kl x kl].
+  const int dlo = NEG ? -(r0 + 31) : r0 - (kl - 1);
+  const int dhi = NEG ? (kl - 1 - r0) : (r0 + 31);
   const int rbase = (int)a.relidx[clampi(dlo + S - 1, 0, hi)] & ~7;
+  const int rtop = (int)a.relidx[clampi(dhi + S - 1, 0, hi)];
+  const int nks = min((rtop - rbase + 32) / 32, a.Wg / 32);
+  const int izero = (int)a.relidx[S - 1];  // idx(0)
+  {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int vpr = nks * 8;  // 16-byte vectors per row
+    for (int t = tid; t < 32 * vpr; t += 128) *(f32x4*)(G + (t / vpr) * LDG + (t % vpr) * 4) = z4;
+  }
+  attn::load_idx_padded(idx, a.relidx, S, Sp, tid, 128);
+  // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here
+  for (int id = tid; id < a.rcnt * 4; id += 128) {
+    const int r = a.rmin + (id >> 2);
+    if (r < rbase || r >= rbase + nks * 32) *(bf16x8*)(gt + (long)id * 8) = z8;
+  }
   const long xbase = (((long)b * a.nh + h) * Sp + row) * Sp;
   f32x4 acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int kl = a.klen ? min(a.klen[b], S) : S;
-  const int nct = (r0 < kl) ? (kl + 63) / 64 : 0;  // dS is only defined (and non-zero) inside [kl x kl]
-  bf16x8 xb[2], yst[4];
-  auto load_ct = [&](int ct) {
+  const int nct = (kl + 63) / 64;
+  const bf16* ytb = a.YT + h * a.y_sh + b * a.y_sb + (long)c * a.y_sd + g * 8;
+  const int16_t* ib = idx + (NEG ? (Sp - 1 - row + g * 8) : (Sp - 1 + row - g * 8));  // idx(delta) = ib[+-(col - g*8)]
+  float* grow = G + rl * LDG - rbase;  // indexed by the absolute table row
+  const int wmax = rbase + nks * 32 - 1;
+  const int dummy = rbase + a.Wg;      // the row's 4 padding floats: never read
+  // lane-linear part of the identity-band slot: slot = izero + delta, delta = +-(row - col)
+  const int lin0 = izero + (NEG ? (g * 8 - row) : (row - g * 8));
+  const int rw = r0 + w * 16;
+  struct Frags { bf16x8 y[8], x[2]; };
+  auto load_ct = [&](int ct, Frags& F) {
     const int c0 = ct * 64;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int id = tid + t * 128;
-      yst[t] = *(const bf16x8*)(a.YT + h * a.y_sh + b * a.y_sb + (id >> 3) * a.y_sd + c0 + (id & 7) * 8);
-    }
-    xb[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
-    xb[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) F.y[kk * 4 + dt] = *(const bf16x8*)(ytb + (long)(dt * 16) * a.y_sd + c0 + kk * 32);
+    F.x[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
+    F.x[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
   };
-  if (nct > 0) load_ct(0);
-  for (int ct = 0; ct < nct; ++ct) {
+  auto step = [&](int ct, const Frags& F) {
     const int c0 = ct * 64;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int id = tid + t * 128;
-      *(bf16x8*)(smem + C_YT + (id >> 3) * (LDV * 2) + (id & 7) * 16) = yst[t];
-    }
-    const bf16x8 x0 = xb[0], x1 = xb[1];
-    __syncthreads();
-    if (ct + 1 < nct) load_ct(ct + 1);
+    // delta range of this wave's 16 rows x these 64 columns (wave-uniform)
+    const int d_a = rw - (c0 + 63), d_b = rw + 15 - c0;  // row - col in [d_a, d_b]
+    const bool band = max(abs(d_a), abs(d_b)) < a.lin;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 xv = kk ? x1 : x0;
+      const bf16x8 xv = F.x[kk];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 af = *(const bf16x8*)(smem + C_YT + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 8) * 2);
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xv, acc[dt], 0, 0, 0);
-      }
-      int gi[8];
-      bool uniq[8];
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.y[kk * 4 + dt], xv, acc[dt], 0, 0, 0);
+      const int cb = c0 + kk * 32;  // this lane's columns: cb + g*8 + e
+      if (band) {
+        const int s0 = NEG ? (lin0 + cb) : (lin0 - cb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = c0 + kk * 32 + g * 8 + e;
-        const int dlt = NEG ? (col - row) : (row - col);
-        gi[e] = clampi((int)idx[clampi(dlt + S - 1, 0, hi)] - rbase, 0, a.Wg - 1);
-        uniq[e] = abs(dlt) < a.lin;
-      }
+        for (int e = 0; e < 8; ++e) {
+          const float x = bf2f(xv[e]);
+          const int slot = NEG ? (s0 + e) : (s0 - e);
+          grow[x != 0.f ? slot : dummy] = x;  // injective inside the band and G starts at 0: a plain store is exact
+        }
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {  // ~2/3 of dS is exactly 0 (padding / masks) and is skipped
-        const float x = bf2f(xv[e]);
-        if (x != 0.f) {
-          // identity-bucket region: (row, col) -> slot is injective and G starts at 0, so a plain store is exact;
-          // LDS fp32 atomics (~190 cycles per wave instruction) are kept for the log-bucket region only
-          if (uniq[e]) G[rl * LDG + gi[e]] = x;
-          else atomicAdd(&G[rl * LDG + gi[e]], x);
+        for (int e = 0; e < 8; ++e) {  // ~2/3 of dS is exactly 0 (padding / masks) and is skipped
+          const float x = bf2f(xv[e]);
+          if (x != 0.f) {
+            const int dlt = NEG ? (cb + g * 8 + e - row) : (row - cb - g * 8 - e);
+            const int gi = clampi((int)(NEG ? ib[cb + e] : ib[-(cb + e)]), rbase, wmax);
+            // LDS fp32 atomics (~190 cycles per wave instruction) only where log buckets can collide
+            if (abs(dlt) < a.lin) grow[gi] = x;
+            else atomicAdd(&grow[gi], x);
+          }
         }
       }
     }
-    __syncthreads();
+  };
+  {
+    Frags F0, F1;
+    load_ct(0, F0);
+    for (int ct = 0; ct < nct; ct += 2) {
+      if (ct + 1 < nct) load_ct(ct + 1, F1);
+      step(ct, F0);
+      if (ct + 2 < nct) load_ct(ct + 2, F0);
+      if (ct + 1 < nct) step(ct + 1, F1);
+    }
   }
-  // ---- table part: acc[d][row] += sum_r PT[d][rbase + r] * G[row][r], PT fragments double-buffered from L2
-  const int nks = a.Wg / 32;
+  // ---- table part: acc[d][row] += sum_r PT[d][rbase + r] * G[row][r], PT fragments double-buffered from L2;
+  //      G^T[r][row] leaves via two identity MFMAs per 32 table rows
   const bf16* pt = a.PT + (long)h * 64 * a.span2 + rbase + g * 8;
+  bf16x8 I0, I1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    I0[e] = f2bf((g * 8 + e) == c ? 1.f : 0.f);
+    I1[e] = f2bf((g * 8 + e) == c + 16 ? 1.f : 0.f);
+  }
   auto load_pt = [&](int kk, bf16x8* dstf) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const bool ok = rbase + kk * 32 + g * 8 + 8 <= a.span2;
-      dstf[dt] = ok ? *(const bf16x8*)(pt + (long)(dt * 16 + c) * a.span2 + kk * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      dstf[dt] = ok ? *(const bf16x8*)(pt + (long)(dt * 16 + c) * a.span2 + kk * 32) : z8;
     }
   };
   auto table_step = [&](int kk, const bf16x8* af) {
@@ -426,10 +461,18 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfv, acc[dt], 0, 0, 0);
+    const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I0, zf, 0, 0, 0);  // [row g*4+j][table row kk*32 + c]
+    const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I1, zf, 0, 0, 0);  // [row g*4+j][table row kk*32+16+c]
+    const int ra = rbase + kk * 32 + c - a.rmin, rb = ra + 16;
+    if (ra >= 0 && ra < a.rcnt)
+      *(bf16x4*)(gt + (long)ra * 32 + w * 16 + g * 4) = (bf16x4){f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3])};
+    if (rb >= 0 && rb < a.rcnt)
+      *(bf16x4*)(gt + (long)rb * 32 + w * 16 + g * 4) = (bf16x4){f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
   };
   bf16x8 pa[4], pb[4];
-  if (nct > 0) load_pt(0, pa);
-  for (int kk = 0; kk < (nct > 0 ? nks : 0); kk += 2) {
+  load_pt(0, pa);
+  for (int kk = 0; kk < nks; kk += 2) {
     if (kk + 1 < nks) load_pt(kk + 1, pb);
     table_step(kk, pa);
     if (kk + 2 < nks) load_pt(kk + 2, pa);
@@ -440,21 +483,6 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
-  }
-  // ---- G^T block of this workgroup: GT[h][b][tile][r][32 rows] (bf16), r = table row - rmin, zero outside
-  // [rbase, rbase+Wg).  One contiguous rcnt*64-byte block: thread -> (r, 8-row chunk) = consecutive 16 bytes.
-  {
-    bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
-    for (int id = tid; id < a.rcnt * 4; id += 128) {
-      const int r = a.rmin + (id >> 2), ch = id & 3;
-      const int gr = r - rbase;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (gr >= 0 && gr < a.Wg) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(G[(ch * 8 + e) * LDG + gr]);
-      }
-      *(bf16x8*)(gt + (long)id * 8) = v;
-    }
   }
 }
 
