@@ -57,13 +57,19 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0>
+// MI_: 16-row MFMA tiles per wave along M.  The tile is (32*MI_) x (32*NW); MI_ = NW gives the square 128/256 tiles,
+// MI_ = 7 with NW = 8 a 224x256 tile for shapes whose 256x256 grid leaves CUs idle (8512 rows = 38 x 224 exactly:
+// 228 tiles on 256 CUs for N = 1536 instead of 204 bigger ones).  LDS keeps the 32*NW-row A image; the unused rows are
+// simply not fetched.
+template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0, int MI_ = NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   using Cfg = TileCfg<NW>;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
+  constexpr int MI = MI_;           // 16-row MFMA tiles per wave along M; 4 tiles (64 cols) along N
+  constexpr int BM = 32 * MI;
   constexpr int WC = NW / 2;        // waves along N (2 rows of waves along M)
-  constexpr int MI = BM / 2 / 16;   // 16-row MFMA tiles per wave along M (4 or 8); 4 tiles (64 cols) along N
   constexpr int WROWS = MI * 16;    // rows of C per wave
+  static_assert(SCHED == 0 || MI_ == NW, "the counted-vmcnt schedules assume the square tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int off = (q * NW + wave) * 1024;
-      glds16(a_src[q] + koff_a, base + off);
+      if ((q * NW + wave) * 8 < BM) glds16(a_src[q] + koff_a, base + off);  // (always true for the square tiles)
       glds16(b_src[q] + koff, base + TILE_BYTES + off);
     }
   };
@@ -217,15 +223,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
   }
   const bool full = (n4 + 3 < g.N);
 #pragma unroll
-  for (int half = 0; half < MI / 4; ++half) {  // the wave tile leaves in slabs of 64 rows
+  for (int half = 0; half < (MI + 3) / 4; ++half) {  // the wave tile leaves in slabs of (up to) 64 rows
+    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
+      if (half * 4 + mi < MI) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+        for (int ni = 0; ni < 4; ++ni)
+          *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+      }
     if (n4 < g.N) {
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < cnt * 4; ++it) {
       const int row = it * 4 + er;
       const int m = m0 + wm * WROWS + half * 64 + row;
       if (m >= g.M) continue;
@@ -476,13 +485,31 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   }
   const bool use_big = big && splitk_ws_floats != -2;  // -2: remainder rows of a split launch -> 128x128 tiles
   const int BT = use_big ? 256 : 128;
-  g.tiles_m = (M + BT - 1) / BT;
+  // 224x256 tiles when they cover the problem in fewer (rounds x tile area) than 256x256 -- the N = 1536 GEMMs of the
+  // step: 38 x 6 = 228 tiles in one round instead of 204 tiles that are 14 % bigger
+  bool use_224 = false;
+  static const int no224 = getenv("FBL_GEMM_NO224") ? atoi(getenv("FBL_GEMM_NO224")) : 0;
+  if (use_big && splitk_ws_floats >= 0 && !no224) {
+    int dev = 0, n_cu = 256;
+    static int cu_cached = 0;
+    if (!cu_cached) {
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cu_cached = prop.multiProcessorCount;
+      if (cu_cached <= 0) cu_cached = 256;
+    }
+    n_cu = cu_cached;
+    const long tn = (N + 255) / 256;
+    const long t256 = tn * ((M + 255) / 256), t224 = tn * ((M + 223) / 224);
+    const long c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+    use_224 = c224 * 100 < c256 * 97;
+  }
+  g.tiles_m = use_224 ? (M + 223) / 224 : (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
-#define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_)                                                                \
+#define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_, MI_)                                                           \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \
-    auto kfn = gemm_bf16_nt_kernel<NW_, ACT_, AUX_, SK_>;                                                      \
+    auto kfn = gemm_bf16_nt_kernel<NW_, ACT_, AUX_, SK_, 0, MI_>;                                              \
     constexpr int smem_bytes = TileCfg<NW_>::SMEM_BYTES;                                                       \
     if (!attr_set) {                                                                                           \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes); \
@@ -491,10 +518,11 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, dim3(NW_ * 64), smem_bytes, (hipStream_t)stream, g);                         \
   } while (0)
-#define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                         \
-  do {                                                           \
-    if (use_big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false);       \
-    else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_);                 \
+#define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                              \
+  do {                                                                \
+    if (use_224) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 7);         \
+    else if (use_big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 8);    \
+    else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_, 4);                   \
   } while (0)
 #define FBL_GEMM_LAUNCH_SCHED(SCHED_)                                                                          \
   do {                                                                                                         \
