@@ -318,6 +318,87 @@ def g7_misc(misc):
     npz("G7_misc", **out)
 
 
+def load_bert():
+    """model/bert.py under transformers 5."""
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+    mu.find_pruneable_heads_and_indices = None
+    orig = mu.PreTrainedModel.get_extended_attention_mask
+
+    def gem(self, mask, shape, device=None, dtype=None):
+        # the reference pins transformers 4.17: (1 - mask) * -10000 (v5 would use finfo.min; identical after softmax
+        # unless a row is fully masked)
+        return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+
+    mu.PreTrainedModel.get_extended_attention_mask = gem
+    mu.PreTrainedModel.get_head_mask = lambda self, hm, n, *a: [None] * n
+    spec = importlib.util.spec_from_file_location("model.bert", os.path.join(REF, "model/bert.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["model.bert"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_ref_bert(bert, cfg, P):
+    from transformers import BertConfig
+
+    hc = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                    num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                    max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                    layer_norm_eps=cfg.layer_norm_eps, pad_token_id=cfg.pad_token_id)
+    m = bert.BertForMaskedLM(hc, max_feats=cfg.max_feats, features_dim=cfg.features_dim, freeze_lm=True, ft_ln=True, freeze_mlm=True,
+                             n_ans=cfg.n_ans, freeze_last=True)
+    sd = m.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    extra = [k for k in sd if k not in P and "position_ids" not in k and "decoder" not in k and "pooler" not in k]
+    assert not extra, extra
+    m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=False)
+    # transformers-4.17 tie_weights semantics (not applied under shim 1)
+    m.cls.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    m.cls.predictions.decoder.bias = m.cls.predictions.bias
+    m.eval()
+    return m
+
+
+def g8_bert():
+    """Config 1 (BERT variant, CPU reference path): tiny config with full tensors + BERT-base dims (seed recipe)."""
+    from oracle.bert_oracle import BertOracleConfig, synth_params
+
+    bert = load_bert()
+    tiny = BertOracleConfig(vocab_size=211, hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                            max_position_embeddings=64, features_dim=24, max_feats=4)
+    P = synth_params(tiny, seed=8, std=0.3, ln_jitter=0.1)
+    m = build_ref_bert(bert, tiny, P)
+    b = synth_batch(tiny, B=3, L=12, seed=81)
+    with torch.no_grad():
+        out = m(**b, output_hidden_states=True)
+        out_nv = m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"])
+    npz("G8_bert_tiny", **{"P/" + k: v for k, v in P.items()}, **{"in/" + k: v for k, v in b.items()},
+        logits=out.logits, loss=out.loss, hidden_last=out.hidden_states[-1], hidden_emb=out.hidden_states[0],
+        logits_text_only=out_nv.logits, loss_text_only=out_nv.loss)
+    # BASELINE configs[0]: BERT-base, B=4, T=10 x 768, L=64, ids ~ U[1000, 30522), all-ones masks
+    cfg = BertOracleConfig()
+    P = synth_params(cfg, seed=0)
+    m = build_ref_bert(bert, cfg, P)
+    g = torch.Generator().manual_seed(18)
+    video = torch.randn(4, 10, 768, generator=g)
+    ids = torch.randint(1000, 30522, (4, 64), generator=g)
+    sel = torch.rand(4, 64, generator=g) < 0.15
+    sel[:, 1] = True
+    labels = torch.where(sel, ids, torch.full_like(ids, -100))
+    with torch.no_grad():
+        out = m(video=video, video_mask=torch.ones(4, 10, dtype=torch.long), input_ids=ids,
+                attention_mask=torch.ones(4, 64, dtype=torch.long), labels=labels)
+    lg = out.logits
+    npz("G8_bert_base", seed=np.array([0]), batch_seed=np.array([18]), loss=out.loss,
+        logits_slice=lg[:, ::7, ::499].contiguous(), logits_sum=lg.double().sum(), logits_abs_sum=lg.double().abs().sum(),
+        logits_row0=lg[0, 12, :2048].contiguous(), argmax=lg.argmax(-1), top5=lg.topk(5, -1).indices[:, ::5].contiguous())
+
+
 def g9_answers(deberta):
     from oracle.deberta_oracle import synth_params
 
@@ -354,6 +435,7 @@ def main():
         "G5": lambda: g5_tiny_model(deberta),
         "G6": lambda: g6_xlarge(deberta),
         "G7": lambda: g7_misc(misc),
+        "G8": g8_bert,
         "G9": lambda: g9_answers(deberta),
     }
     for k, fn in jobs.items():

@@ -150,3 +150,51 @@ def test_g9_answer_head(golden):
     assert maxabs(out["logits"], g["logits"]) < 5e-5
     top10 = out["logits"].softmax(-1).topk(10, -1).indices
     assert torch.equal(top10, g["top10"])
+
+
+# ---------------------------------------------------------------------------------- config 1: BERT variant (row a25)
+def test_g8_bert_tiny(golden):
+    from oracle import bert_oracle as BO
+
+    g = golden("G8_bert_tiny")
+    P = {k[2:]: v for k, v in g.items() if k.startswith("P/")}
+    b = {k[3:]: v for k, v in g.items() if k.startswith("in/")}
+    cfg = BO.BertOracleConfig(vocab_size=211, hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                              max_position_embeddings=64, features_dim=24, max_feats=4)
+    assert set(P) == set(BO.param_shapes(cfg)), "state_dict key map"
+    emb = BO.embeddings(cfg, P, b["input_ids"], b["video"])
+    assert maxabs(emb, g["hidden_emb"]) < 2e-5
+    out = BO.forward(cfg, P, b["input_ids"], b["attention_mask"], b["video"], b["video_mask"], b["labels"])
+    assert maxabs(out["hidden"], g["hidden_last"]) < 5e-5
+    assert maxabs(out["logits"], g["logits"]) < 1e-4
+    assert abs(out["loss"].item() - g["loss"].item()) < 1e-5
+    assert torch.equal(out["logits"].argmax(-1), g["logits"].argmax(-1))
+    out = BO.forward(cfg, P, b["input_ids"], b["attention_mask"], labels=b["labels"])
+    assert maxabs(out["logits"], g["logits_text_only"]) < 1e-4
+    assert abs(out["loss"].item() - g["loss_text_only"].item()) < 1e-5
+
+
+@pytest.mark.slow
+def test_g8_bert_base_config1(golden):
+    """BASELINE configs[0]: BERT-base, 4 synthetic videos (T=10 x 768), L=64, MLM forward on the CPU path."""
+    from oracle import bert_oracle as BO
+
+    g = golden("G8_bert_base")
+    cfg = BO.BertOracleConfig()
+    P = BO.synth_params(cfg, seed=int(g["seed"][0]))
+    gen = torch.Generator().manual_seed(int(g["batch_seed"][0]))
+    video = torch.randn(4, 10, 768, generator=gen)
+    ids = torch.randint(1000, 30522, (4, 64), generator=gen)
+    sel = torch.rand(4, 64, generator=gen) < 0.15
+    sel[:, 1] = True
+    labels = torch.where(sel, ids, torch.full_like(ids, -100))
+    with torch.no_grad():
+        out = BO.forward(cfg, P, ids, torch.ones(4, 64, dtype=torch.long), video, torch.ones(4, 10, dtype=torch.long), labels)
+    lg = out["logits"]
+    assert lg.shape == (4, 74, 30522)
+    assert maxabs(lg[:, ::7, ::499], g["logits_slice"]) < 1e-4
+    assert maxabs(lg[0, 12, :2048], g["logits_row0"]) < 1e-4
+    assert abs(lg.double().sum().item() - g["logits_sum"].item()) < 1e-5 * g["logits_abs_sum"].item()
+    assert abs(out["loss"].item() - g["loss"].item()) < 1e-5
+    assert torch.equal(lg.argmax(-1), g["argmax"])  # token indices bit-exact
+    assert torch.equal(lg.topk(5, -1).indices[:, ::5], g["top5"])
