@@ -306,11 +306,16 @@ class Engine:
                "logits_event": getattr(run, "logits_event", None)}
         if want_hidden:
             res["hidden_states"] = run.hidden_out
-        if full_labels is not None:
-            if need_grad:
-                res["loss"] = _StepFn.apply(self, run, loss_t, *[self.named[n] for n in self.order])
-            else:
-                res["loss"] = loss_t
+        if need_grad and res["logits"] is not None:
+            # one autograd node for the whole model; both outputs are differentiable: the loss (MLM training,
+            # main.py:67-84) and the logits (downstream fine-tuning computes its own loss on them, videoqa.py:66-83,
+            # mc.py:64-92)
+            lt = loss_t if loss_t is not None else torch.zeros((), dtype=F32, device=self.dev)
+            loss_o, logits_o = _StepFn.apply(self, run, lt, res["logits"], *[self.named[n] for n in self.order])
+            res["logits"] = logits_o
+            res["loss"] = loss_o if full_labels is not None else None
+        elif full_labels is not None:
+            res["loss"] = loss_t
         return res
 
     # ------------------------------------------------------------------ forward
@@ -676,8 +681,38 @@ class Engine:
         pst = disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True)
         return dqkv, pst
 
-    def backward(self, run, gloss: torch.Tensor):
-        """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views)."""
+    def _head_bwd(self, run, rows, dlog, dq, all_rows=False):
+        """Backward of the prediction head for the rows `rows` (int32 indices into the N token rows) given their bf16
+        logit gradients dlog [R, Vp]: dq[rows] += d/d(head input).  Head LayerNorm gradients are accumulated."""
+        H, dev = self.H, self.dev
+        R, Vp = dlog.shape
+        Vout = run.Vout
+        if Vout == self.V:
+            tableT = self.ETb
+        else:
+            tableT = torch.zeros(H, Vp, dtype=BF16, device=dev)
+            tableT[:, :Vout] = self.Ansb.t()
+        dhl = torch.zeros(R, H, dtype=F32, device=dev)
+        if R >= 2048:  # enough rows to fill the chip without splitting K
+            L.gemm(dlog, tableT, out_f32=dhl)
+        else:  # few rows, long K -> split-K so the grid covers the chip (accumulates into zeros)
+            L.gemm(dlog, tableT, out_f32=dhl, splitk=max(2, min(16, Vp // 8192)), ws=self.sk_ws)
+        rl = rows.long()
+        hn = run.head_norm
+        sub = NormRef(hn.t[rl].contiguous(), hn.stats[rl].contiguous(), hn.gamma, hn.beta)
+        dt, _ = self._ln_bwd("lm_predictions.lm_head.LayerNorm", dhl, sub, 0.0, 0, want_dy_bf16=False)
+        dpre = torch.empty(R, H, dtype=BF16, device=dev)
+        L.dropout_gelu_bwd(dt, run.head_pre[rl].contiguous(), 0.0, 0, out_bf16=dpre)
+        dqr = torch.empty(R, H, dtype=F32, device=dev)
+        L.gemm(dpre, self.WhT, out_f32=dqr)
+        if all_rows:
+            dq.add_(dqr)
+        else:
+            L.scatter_rows_f32(dqr, rows, dq)  # first contribution: dq is still zero at these rows
+
+    def backward(self, run, gloss: Optional[torch.Tensor], glogits: Optional[torch.Tensor] = None):
+        """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views).  gloss: gradient
+        of the internal MLM loss (or None); glogits: gradient w.r.t. the returned logits [B,S,Vout] (or None)."""
         if not run.save:
             raise RuntimeError("forward was run without gradient bookkeeping")
         cfg, H, dev = self.cfg, self.H, self.dev
@@ -696,38 +731,30 @@ class Engine:
                 reducer.finish()
 
         red = _Ready() if reducer is not None else None
-        # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
-        compact = getattr(run, "logits_c", None) is not None or getattr(run, "rows_i32", None) is not None
-        rows = run.rows_i32 if compact else torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
-        R = rows.numel()
         dq = torch.zeros(N, H, dtype=F32, device=dev)
-        if R > 0:
-            Vout = run.Vout
-            Vp = _ru(Vout, 64)
-            dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
-            if compact:  # logits of the labelled rows only (training path)
-                ar = torch.arange(R, dtype=torch.int32, device=dev)
-                L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
-            else:
-                L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
-            if Vout == self.V:
-                tableT = self.ETb
-            else:
-                tableT = torch.zeros(H, Vp, dtype=BF16, device=dev)
-                tableT[:, :Vout] = self.Ansb.t()
-            # [R x H x Vp]: few rows, K = 128128 -> split-K so the grid covers the chip (accumulates into zeros)
-            dhl = torch.zeros(R, H, dtype=F32, device=dev)
-            L.gemm(dlog, tableT, out_f32=dhl, splitk=max(2, min(16, Vp // 8192)), ws=self.sk_ws)
+        Vout = run.Vout
+        Vp = _ru(Vout, 64)
+        # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
+        if gloss is not None and run.labels is not None:
+            compact = getattr(run, "logits_c", None) is not None or getattr(run, "rows_i32", None) is not None
+            rows = run.rows_i32 if compact else torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
+            R = rows.numel()
+            if R > 0:
+                dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
+                if compact:  # logits of the labelled rows only (training path)
+                    ar = torch.arange(R, dtype=torch.int32, device=dev)
+                    L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+                else:
+                    L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+                self._head_bwd(run, rows, dlog, dq)
+                del dlog
+        # ---- gradient handed in on the logits themselves (downstream losses): every token row
+        if glogits is not None:
+            gl = glogits.reshape(N, Vout)
+            dlog = torch.zeros(N, Vp, dtype=BF16, device=dev) if Vp != Vout else torch.empty(N, Vp, dtype=BF16, device=dev)
+            dlog[:, :Vout].copy_(gl)
+            self._head_bwd(run, torch.arange(N, dtype=torch.int32, device=dev), dlog, dq, all_rows=True)
             del dlog
-            rl = rows.long()
-            hn = run.head_norm
-            sub = NormRef(hn.t[rl].contiguous(), hn.stats[rl].contiguous(), hn.gamma, hn.beta)
-            dt, _ = self._ln_bwd("lm_predictions.lm_head.LayerNorm", dhl, sub, 0.0, 0, want_dy_bf16=False)
-            dpre = torch.empty(R, H, dtype=BF16, device=dev)
-            L.dropout_gelu_bwd(dt, run.head_pre[rl].contiguous(), 0.0, 0, out_bf16=dpre)
-            dqr = torch.empty(R, H, dtype=F32, device=dev)
-            L.gemm(dpre, self.WhT, out_f32=dqr)
-            L.scatter_rows_f32(dqr, rows, dq)
         if red:
             red.ready("head")
         run.dR = torch.zeros(self.span2, H, dtype=F32, device=dev)
@@ -854,12 +881,15 @@ class _StepFn(torch.autograd.Function):
     gradients straight into the flat grad buffer (p.grad views), so autograd itself accumulates nothing."""
 
     @staticmethod
-    def forward(ctx, engine, run, loss_t, *params):
+    def forward(ctx, engine, run, loss_t, logits_t, *params):
         ctx.engine, ctx.run = engine, run
-        return loss_t.detach().clone()
+        ctx.set_materialize_grads(False)
+        return loss_t.detach().clone(), logits_t.detach()
 
     @staticmethod
-    def backward(ctx, gloss):
+    def backward(ctx, gloss, glogits):
         eng, run = ctx.engine, ctx.run
-        eng.backward(run, gloss)
-        return (None, None, None) + tuple(None for _ in eng.order)
+        if gloss is None and glogits is None:
+            return (None, None, None, None) + tuple(None for _ in eng.order)
+        eng.backward(run, gloss, glogits)
+        return (None, None, None, None) + tuple(None for _ in eng.order)

@@ -1,0 +1,125 @@
+"""Multiple-choice VideoQA loops with the reference's signatures and return values (mc.py:25-231) -- BASELINE config 5.
+
+One forward per answer candidate over the same video prefix (S up to 512 with ASR context), the 2-way Yes/No answer
+head read at the ``[MASK]`` row, ``softmax[:, 0]`` as the candidate's score; balanced BCE for training.  Under data
+parallelism the gradient exchange waits for the last candidate's backward (``GradReducer.accumulate``).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import sys
+from functools import reduce
+
+import torch
+import torch.nn.functional as F
+
+from .optim import FusedAdam
+from .util import dist
+from .util.metrics import MetricLogger
+from .util.misc import adjust_learning_rate, get_mask
+from .videoqa import mask_row_logits
+
+
+def candidate_scores(model, tokenizer, batch_dict, device, args):
+    """mc.py:44-72,140-165: text[aid] is the batch of candidate `aid`; returns scores [B, n_candidates]."""
+    video = batch_dict["video"].to(device)
+    video_mask = get_mask(batch_dict["video_len"], video.size(1)).to(device)
+    text = batch_dict["text"]
+    scores = []
+    for aid in range(len(text)):  # one forward per answer candidate id
+        encoded = tokenizer(text[aid], add_special_tokens=True, max_length=args.max_tokens, padding="longest",
+                            truncation=True, return_tensors="pt")
+        output = model(video=video, video_mask=video_mask, input_ids=encoded["input_ids"].to(device),
+                       attention_mask=encoded["attention_mask"].to(device))
+        logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
+        scores.append(logits.softmax(-1)[:, 0])
+    return torch.stack(scores, 1)
+
+
+def mc_loss(scores, gt, n_choices):
+    """mc.py:75-92: balanced BCE over the positive and the negative candidates (plain BCE for a single candidate)."""
+    if n_choices > 1:
+        pos = scores[torch.arange(len(scores), device=scores.device), gt]
+        neg_mask = torch.ones_like(scores)
+        neg_mask.scatter_(1, gt.unsqueeze(-1), 0)
+        neg = scores[neg_mask.bool()].view(len(scores), n_choices - 1).view(-1)
+        pos_loss = F.binary_cross_entropy(pos, torch.ones_like(pos))
+        neg_loss = F.binary_cross_entropy(neg, torch.zeros_like(neg))
+        return (pos_loss + neg_loss) / 2
+    return F.binary_cross_entropy(scores.squeeze(1), gt.float())
+
+
+def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, args, max_norm: float = 0):
+    model.train()
+    metric_logger = MetricLogger(delimiter="  ")
+    header = "Epoch: [{}]".format(epoch)
+    num_training_steps = int(len(data_loader) * args.epochs)
+    reducer = getattr(model.engine(), "reducer", None) if hasattr(model, "engine") else None
+    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+        scores = candidate_scores(model, tokenizer, batch_dict, device, args)
+        loss = mc_loss(scores, batch_dict["answer_id"].to(device), data_loader.dataset.mc)
+        loss_dict_reduced = dist.reduce_dict({"cls_loss": loss})
+        loss_value = sum(loss_dict_reduced.values()).item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            print(loss_dict_reduced)
+            sys.exit(1)
+        optimizer.zero_grad()
+        with (reducer.accumulate() if reducer is not None else contextlib.nullcontext()):
+            loss.backward()
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step(clip_max_norm=max_norm)
+        else:
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            optimizer.step()
+        adjust_learning_rate(optimizer, curr_step=epoch * len(data_loader) + i_batch,
+                             num_training_steps=num_training_steps, args=args)
+        metric_logger.update(loss=loss_value, **loss_dict_reduced)
+        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(model, tokenizer, data_loader, device, dataset_name, args, split="test", type_map={0: "all"}):
+    model.eval()
+    metric_logger = MetricLogger(delimiter="  ")
+    header = f"{split}:"
+    res = {}
+    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+        scores = candidate_scores(model, tokenizer, batch_dict, device, args)
+        preds = scores.round().long().squeeze(1) if scores.shape[1] == 1 else scores.max(1).indices
+        qids, types = batch_dict["qid"], batch_dict["type"]
+        if batch_dict["answer_id"][0].item() != -1:
+            answer_id = batch_dict["answer_id"].to(device)
+            agreeings = preds == answer_id
+            for i, (qid, gt, pred, type_) in enumerate(zip(qids, answer_id, preds, types)):
+                res[qid] = {"pred": pred.item(), "gt": gt.item()}
+                if type_map is not None and len(type_map) > 1:
+                    res[qid]["type"] = int(type_)
+                res[qid]["acc"] = agreeings[i].item()
+            dico_reduced = dist.reduce_dict({"acc": agreeings.sum() / len(qids)})
+            metric_logger.update(acc=dico_reduced["acc"].item())
+        else:  # hidden test set: predictions only (mc.py:205-207)
+            for qid, pred in zip(qids, preds):
+                res[str(qid)] = int(pred.item())
+    all_res = dist.all_gather(res)
+    results = reduce(lambda a, b: a.update(b) or a, all_res, {})
+    assert len(results) == len(data_loader.dataset)
+    if isinstance(next(iter(results.values())), dict):
+        acc = sum(int(results[qid]["acc"]) for qid in results) / len(results)
+        acc_type = None
+        if type_map is not None and len(type_map) > 1:
+            acc_type = {type_map[i]: sum(results[qid]["acc"] for qid in results if results[qid]["type"] == i)
+                        / len([x for x in results.values() if x["type"] == i]) for i in type_map}
+        if dist.is_main_process():
+            print(dataset_name)
+            print(f"{split} acc: {acc: .2%}")
+            if acc_type is not None:
+                for x in acc_type:
+                    print(f"acc {x}: {acc_type[x]: .2%}")
+        return results, acc
+    return results, 0

@@ -175,6 +175,9 @@ class DebertaV2ForMaskedLM(nn.Module):
             raise NotImplementedError(
                 "the MI355X path implements FrozenBiLM's frozen-LM regime (freeze_lm=freeze_mlm=True): "
                 "only linear_video, adapters and LayerNorms receive gradients")
+        if n_ans and not freeze_last:
+            raise NotImplementedError("--ft_last (trainable answer-embedding module) is not implemented: the answer "
+                                      "head is used frozen, the reference's default (args.py:358-363)")
 
         shapes = param_shapes(cfg, features_dim, ds_factor_attn, ds_factor_ff, n_ans)
         g = torch.Generator().manual_seed(0)
@@ -231,6 +234,8 @@ class DebertaV2ForMaskedLM(nn.Module):
     def set_answer_embeddings(self, a2tok, freeze_last=True):
         """model/deberta.py:1358-1380: answer table = masked mean of the word embeddings of each answer's tokens.
         (The reference assigns ``answer_bias.weight``, an attribute, so the effective bias keeps its value.)"""
+        if not freeze_last:
+            raise NotImplementedError("--ft_last (trainable answer-embedding module) is not implemented")
         E = self.get_param("deberta.embeddings.word_embeddings.weight")
         pad = self.config.pad_token_id
         a2tok = a2tok.to(E.device)

@@ -9,6 +9,7 @@ parameters never enter a bucket: 120.5 MB fp32 per step at DeBERTa-v2-XLarge, ~2
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -25,6 +26,7 @@ class GradReducer:
         self.cursor = 0
         self.pending: List = []
         self.launched: List[tuple] = []
+        self._held = False
 
     @classmethod
     def attach(cls, model, group=None, **kw) -> "GradReducer":
@@ -33,7 +35,21 @@ class GradReducer:
         eng.reducer = red
         return red
 
+    @contextlib.contextmanager
+    def accumulate(self):
+        """Several backward passes feed ONE optimizer step (mc.py runs one forward per answer candidate and
+        back-propagates through all of them): buckets are not final until the last pass, so the exchange is held back
+        and done in one go on exit."""
+        self._held = True
+        try:
+            yield self
+        finally:
+            self._held = False
+            self.finish()
+
     def ready(self, key: str):
+        if self._held:
+            return
         end = self.bucket_ends.get(key)
         if end is None or end <= self.cursor:
             return
@@ -49,6 +65,8 @@ class GradReducer:
         self.cursor = end
 
     def finish(self):
+        if self._held:
+            return
         if self.cursor < self.flat_grad.numel():
             self._launch(self.flat_grad.numel())
         for w in self.pending:

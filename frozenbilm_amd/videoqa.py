@@ -1,0 +1,150 @@
+"""Open-ended VideoQA loops with the reference's signatures and return values (videoqa.py:25-245) -- BASELINE config 4.
+
+The model is the same masked-LM forward; the prediction head scores the answer vocabulary (``set_answer_embeddings``)
+and the row of the ``[MASK]`` token is read out.  Fine-tuning back-propagates a loss computed by the caller on the
+returned ``logits`` (they are a differentiable output of the single autograd node of the engine).
+"""
+from __future__ import annotations
+
+import math
+import sys
+from functools import reduce
+
+import torch
+import torch.nn.functional as F
+
+from .optim import FusedAdam
+from .util import dist
+from .util.metrics import MetricLogger
+from .util.misc import adjust_learning_rate, get_mask
+
+
+def _encode(batch_dict, tokenizer, device, args, text=None):
+    video = batch_dict["video"].to(device)
+    video_len = batch_dict["video_len"]
+    video_mask = get_mask(video_len, video.size(1)).to(device)
+    encoded = tokenizer(batch_dict["text"] if text is None else text, add_special_tokens=True, max_length=args.max_tokens,
+                        padding="longest", truncation=True, return_tensors="pt")
+    return video, video_mask, encoded
+
+
+def mask_row_logits(output_logits, encoded_ids, tokenizer, args):
+    """videoqa.py:66-69,163-166: rows of the text part (after the `max_feats` visual slots) where the input is [MASK]."""
+    delay = args.max_feats if args.use_video else 0
+    ids = encoded_ids.to(output_logits.device)
+    return output_logits[:, delay: ids.size(1) + delay][ids == tokenizer.mask_token_id]
+
+
+def vqa_loss(logits, answer_id, dataset_name):
+    """videoqa.py:70-80: soft-label NLL for iVQA / VQA (answer counts /2 resp. /3, clamped to 1), CE otherwise."""
+    if dataset_name in ("ivqa", "vqa"):
+        a = (answer_id / (2 if dataset_name == "ivqa" else 3)).clamp(max=1)
+        nll = -F.log_softmax(logits, 1)
+        return (nll * a / a.sum(1, keepdim=True).clamp(min=1)).sum(dim=1).mean()
+    return F.cross_entropy(logits, answer_id)
+
+
+def topk_agreement(logits, answer_id, dataset_name, thresholds):
+    """videoqa.py:167-195: softmax -> top-k answer ids; exact match, or the iVQA/VQA soft score of the best hit."""
+    probs = logits.softmax(-1)
+    topk_aids = torch.topk(probs, max(thresholds), -1).indices
+    agreeings = {}
+    if dataset_name not in ("ivqa", "vqa"):
+        expanded = answer_id.view(-1, 1).expand_as(topk_aids)
+        gt = answer_id
+        for x in thresholds:
+            agreeings[x] = topk_aids[:, :x] == expanded[:, :x]
+    else:
+        gt = (answer_id / (2 if dataset_name == "ivqa" else 3)).clamp(max=1)
+        for x in thresholds:
+            predicted = F.one_hot(topk_aids[:, :x], num_classes=gt.shape[-1]).sum(1)
+            agreeings[x] = (predicted * gt).max(1)[0]
+    return topk_aids, gt, agreeings
+
+
+def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dataset_name, args, max_norm: float = 0):
+    model.train()
+    metric_logger = MetricLogger(delimiter="  ")
+    header = "Epoch: [{}]".format(epoch)
+    num_training_steps = int(len(data_loader) * args.epochs)
+    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+        video, video_mask, encoded = _encode(batch_dict, tokenizer, device, args)
+        output = model(video=video, video_mask=video_mask, input_ids=encoded["input_ids"].to(device),
+                       attention_mask=encoded["attention_mask"].to(device))
+        logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
+        loss = vqa_loss(logits, batch_dict["answer_id"].to(device), dataset_name)
+        loss_dict_reduced = dist.reduce_dict({"cls_loss": loss})
+        loss_value = sum(loss_dict_reduced.values()).item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            print(loss_dict_reduced)
+            sys.exit(1)
+        optimizer.zero_grad()
+        loss.backward()
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step(clip_max_norm=max_norm)
+        else:
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            optimizer.step()
+        adjust_learning_rate(optimizer, curr_step=epoch * len(data_loader) + i_batch,
+                             num_training_steps=num_training_steps, args=args)
+        metric_logger.update(loss=loss_value, **loss_dict_reduced)
+        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(model, tokenizer, data_loader, device, dataset_name, args, thresholds=[1, 10], split="test",
+             type_map={0: "all"}):
+    model.eval()
+    metric_logger = MetricLogger(delimiter="  ")
+    header = f"{split}:"
+    res = {}
+    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+        video, video_mask, encoded = _encode(batch_dict, tokenizer, device, args)
+        input_ids = encoded["input_ids"].to(device)
+        attention_mask = encoded["attention_mask"].to(device)
+        if not args.suffix and not args.use_context:  # remove sep token if not using the suffix (videoqa.py:152-156)
+            attention_mask[input_ids == tokenizer.sep_token_id] = 0
+            input_ids[input_ids == tokenizer.sep_token_id] = tokenizer.pad_token_id
+        output = model(video=video, video_mask=video_mask, input_ids=input_ids, attention_mask=attention_mask)
+        logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
+        answer_id, qids = batch_dict["answer_id"].to(device), batch_dict["qid"]
+        types = batch_dict["type"]
+        subs = batch_dict["sub"] if "sub" in batch_dict else [0] * len(types)
+        topk_aids, gts, agreeings = topk_agreement(logits, answer_id, dataset_name, thresholds)
+        for i, (qid, gt, pred, type_, sub) in enumerate(zip(qids, gts, topk_aids, types, subs)):
+            res[qid] = {"pred": pred.tolist(), "gt": gt.tolist() if dataset_name in ["ivqa", "vqa"] else gt.item(),
+                        "type": int(type_), "sub": sub}
+            for x in thresholds:
+                res[qid][f"acc{x}"] = agreeings[x][i].sum().detach().cpu().item()
+        dico_reduced = dist.reduce_dict({"acc": agreeings[1].sum() / len(qids)})
+        metric_logger.update(acc=dico_reduced["acc"].item())
+
+    all_res = dist.all_gather(res)
+    results = reduce(lambda a, b: a.update(b) or a, all_res, {})
+    assert len(results) == len(data_loader.dataset)
+    out = {}
+    for x in thresholds:
+        out[f"acc{x}"] = sum(results[qid][f"acc{x}"] for qid in results) / len(results)
+    acc_type = None
+    if type_map is not None and len(type_map) > 1:
+        acc_type = {type_map[i]: sum(results[qid]["acc1"] for qid in results if results[qid]["type"] == i)
+                    / len([x for x in results.values() if x["type"] == i]) for i in type_map}
+    n_sub = len([x for x in results.values() if x["sub"]])
+    acc_sub = sum(results[qid]["acc1"] for qid in results if results[qid]["sub"]) / n_sub if n_sub else None
+    if dist.is_main_process():
+        print(dataset_name)
+        for x in thresholds:
+            print(f"{split} acc{x}: {out[f'acc{x}']: .2%}")
+        if acc_type is not None:
+            for x in acc_type:
+                print(f"acc {x}: {acc_type[x]: .2%}")
+            out.update(acc_type)
+        if n_sub:
+            print(f"acc sub: {acc_sub: .2%}; proportion {n_sub / len(results): .2%}")
+            out["acc_sub"] = acc_sub
+    return results, out

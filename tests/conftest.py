@@ -15,10 +15,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~30 s on CPU")
 
 
-def load_golden(name):
+def load_golden(name, raw=False):
     import torch
 
     z = np.load(os.path.join(GOLD, name + ".npz"))
+    if raw:  # numpy arrays as stored (string entries hold JSON)
+        return {k: z[k] for k in z.files}
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 

@@ -420,6 +420,144 @@ def g9_answers(deberta):
         **{"in." + k: v for k, v in batch.items()})
 
 
+def load_downstream():
+    """The reference's videoqa.py / mc.py modules (loops only) with their heavy imports stubbed out."""
+    sys.modules.setdefault("hostlist", types.ModuleType("hostlist"))  # util/dist.py imports it at module level
+    ds = types.ModuleType("datasets")
+    for n in ("build_videoqa_dataset", "videoqa_collate_fn", "build_mc_dataset", "mc_collate_fn",
+              "build_videotext_dataset", "videotext_collate_fn"):
+        setattr(ds, n, None)
+    saved = sys.modules.get("datasets")
+    sys.modules["datasets"] = ds
+    pkg = sys.modules["model"]
+    pkg.build_model = pkg.get_tokenizer = None
+    sys.path.insert(0, REF)
+    try:
+        mods = []
+        for name in ("videoqa", "mc"):
+            spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, name + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mods.append(mod)
+    finally:
+        sys.path.remove(REF)
+        if saved is not None:
+            sys.modules["datasets"] = saved
+        else:
+            del sys.modules["datasets"]
+    return mods
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+def _downstream_model(deberta, n_ans, seed, max_feats=4):
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg(n_ans=n_ans, max_feats=max_feats, vocab_size=300, max_position_embeddings=128)
+    P = synth_params(cfg, seed=seed, std=0.08, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    g = torch.Generator().manual_seed(seed + 1)
+    a2tok = torch.randint(5, cfg.vocab_size, (n_ans, 3), generator=g)
+    alen = torch.randint(1, 4, (n_ans,), generator=g)
+    a2tok = a2tok * (torch.arange(3)[None] < alen[:, None])
+    m.set_answer_embeddings(a2tok)
+    zero_dropout(m)
+    return cfg, P, m, a2tok
+
+
+def _trainable_state(m):
+    return {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+
+
+def g10_videoqa(deberta, ref_videoqa):
+    """Config 4: the reference's videoqa.py evaluate (msrvtt-style exact match and iVQA soft score) and one epoch of
+    its train_one_epoch (dropout 0, Adam) on synthetic batches -- results dict, metrics, loss and updated parameters."""
+    import json
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_videoqa_batches
+
+    n_ans = 40
+    cfg, P, m, a2tok = _downstream_model(deberta, n_ans, seed=10)
+    tok = StubTokenizer(cfg.vocab_size)
+    args = Args(max_feats=cfg.max_feats)
+    out = {"a2tok": a2tok}
+    for name in ("msrvtt", "ivqa"):
+        batches = make_videoqa_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_ans, n_batches=3, B=4, seed=101,
+                                       dataset_name=name)
+        results, metrics = ref_videoqa.evaluate(m, tok, ListLoader(batches), torch.device("cpu"), name, args,
+                                                thresholds=[1, 10], split="test", type_map={0: "a", 1: "b"})
+        out[f"eval_{name}_results"] = np.array(json.dumps(results))
+        out[f"eval_{name}_metrics"] = np.array(json.dumps({k: float(v) for k, v in metrics.items()}))
+        # raw mask-row probabilities of the first batch, for tolerance-aware comparison of the top-k ids
+        b0 = batches[0]
+        enc = tok(b0["text"])
+        ids, att = enc["input_ids"].clone(), enc["attention_mask"].clone()
+        att[ids == tok.sep_token_id] = 0
+        ids[ids == tok.sep_token_id] = tok.pad_token_id
+        with torch.no_grad():
+            lg = m(video=b0["video"], video_mask=ref_videoqa.get_mask(b0["video_len"], cfg.max_feats), input_ids=ids,
+                   attention_mask=att)["logits"]
+        out[f"eval_{name}_probs0"] = lg[:, cfg.max_feats:][enc["input_ids"] == tok.mask_token_id].softmax(-1)
+    # training: 1 epoch x 3 steps, both loss types
+    for name in ("msrvtt", "ivqa"):
+        cfg, P, m, a2tok = _downstream_model(deberta, n_ans, seed=10)
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95))
+        batches = make_videoqa_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_ans, n_batches=3, B=4, seed=102,
+                                       dataset_name=name)
+        before = _trainable_state(m)
+        stats = ref_videoqa.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device("cpu"), 0, name, args, max_norm=0.1)
+        after = _trainable_state(m)
+        out[f"train_{name}_stats"] = np.array(json.dumps({k: float(v) for k, v in stats.items()}))
+        for key in ("deberta.embeddings.linear_video.weight", "deberta.encoder.layer.1.output.adapter.up.weight",
+                    "deberta.encoder.layer.0.attention.output.adapter.down.weight", "deberta.encoder.LayerNorm.weight"):
+            out[f"train_{name}_delta/{key}"] = after[key] - before[key]
+    npz("G10_videoqa", **out)
+
+
+def g11_mc(deberta, ref_mc):
+    """Config 5: the reference's mc.py evaluate (4-way, Yes/No head) and one epoch of its train_one_epoch."""
+    import json
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_mc_batches
+
+    cfg, P, m, a2tok = _downstream_model(deberta, 2, seed=11)
+    tok = StubTokenizer(cfg.vocab_size)
+    args = Args(max_feats=cfg.max_feats)
+    out = {"a2tok": a2tok}
+    batches = make_mc_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_choices=4, n_batches=3, B=4, seed=111)
+    results, acc = ref_mc.evaluate(m, tok, ListLoader(batches, mc=4), torch.device("cpu"), "how2qa", args)
+    out["eval_results"] = np.array(json.dumps(results))
+    out["eval_acc"] = np.array([acc])
+    hidden = make_mc_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_choices=4, n_batches=1, B=4, seed=112, with_gt=False)
+    results, acc = ref_mc.evaluate(m, tok, ListLoader(hidden, mc=4), torch.device("cpu"), "how2qa", args)
+    out["eval_hidden_results"] = np.array(json.dumps(results))
+    # candidate scores of the first batch
+    b0 = batches[0]
+    sc = []
+    with torch.no_grad():
+        for aid in range(4):
+            enc = tok(b0["text"][aid])
+            lg = m(video=b0["video"], video_mask=ref_mc.get_mask(b0["video_len"], cfg.max_feats), input_ids=enc["input_ids"],
+                   attention_mask=enc["attention_mask"])["logits"]
+            sc.append(lg[:, cfg.max_feats:][enc["input_ids"] == tok.mask_token_id].softmax(-1)[:, 0])
+    out["eval_scores0"] = torch.stack(sc, 1)
+    cfg, P, m, a2tok = _downstream_model(deberta, 2, seed=11)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95))
+    tb = make_mc_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_choices=4, n_batches=3, B=4, seed=113)
+    before = _trainable_state(m)
+    stats = ref_mc.train_one_epoch(m, tok, ListLoader(tb, mc=4), opt, torch.device("cpu"), 0, args, max_norm=0.1)
+    after = _trainable_state(m)
+    out["train_stats"] = np.array(json.dumps({k: float(v) for k, v in stats.items()}))
+    for key in ("deberta.embeddings.linear_video.weight", "deberta.encoder.layer.1.output.adapter.up.weight",
+                "deberta.encoder.layer.0.attention.output.adapter.down.weight", "deberta.encoder.LayerNorm.weight"):
+        out[f"train_delta/{key}"] = after[key] - before[key]
+    npz("G11_mc", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -437,6 +575,8 @@ def main():
         "G7": lambda: g7_misc(misc),
         "G8": g8_bert,
         "G9": lambda: g9_answers(deberta),
+        "G10": lambda: g10_videoqa(deberta, load_downstream()[0]),
+        "G11": lambda: g11_mc(deberta, load_downstream()[1]),
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):
