@@ -558,6 +558,48 @@ def g11_mc(deberta, ref_mc):
     npz("G11_mc", **out)
 
 
+def write_feature_fixture(root, seed=12):
+    """Synthetic WebVid-style inputs: csv (video_id, text) + one fp16 .npy [n_sec, F] per video (one missing, one
+    corrupt).  Deterministic; used by the golden generator and regenerated identically by the tests."""
+    os.makedirs(os.path.join(root, "feats"), exist_ok=True)
+    g = torch.Generator().manual_seed(seed)
+    lens = [3, 10, 11, 25, 1, 47, 10, 7, 0]
+    rows = []
+    for i, n in enumerate(lens):
+        vid = 1000 + i
+        rows.append((vid, f"caption number {i}, with a comma"))
+        if i == 7:
+            continue  # missing file
+        path = os.path.join(root, "feats", f"{vid}.mp4.npy")
+        if n == 0:
+            with open(path, "wb") as f:
+                f.write(b"not a npy file")  # corrupt file
+            continue
+        np.save(path, torch.randn(n, 16, generator=g).half().numpy())
+    import csv as _csv
+
+    with open(os.path.join(root, "data.csv"), "w", newline="") as f:
+        w = _csv.writer(f)
+        w.writerow(["video_id", "text"])
+        w.writerows(rows)
+    return os.path.join(root, "data.csv"), os.path.join(root, "feats")
+
+
+def g12_dataset():
+    """datasets/videotext_dataset.py on the synthetic feature files: items and one collated batch."""
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location("ref_videotext_dataset", os.path.join(REF, "datasets/videotext_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as d:
+        csv_path, feats = write_feature_fixture(d)
+        ds = mod.VideoText_Dataset(csv_path, feats, max_feats=10, features_dim=16)
+        items = [ds[i] for i in range(len(ds))]
+        batch = mod.videotext_collate_fn(items)
+    npz("G12_dataset", video=batch["video"], video_len=batch["video_len"], text=np.array(batch["text"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -577,6 +619,7 @@ def main():
         "G9": lambda: g9_answers(deberta),
         "G10": lambda: g10_videoqa(deberta, load_downstream()[0]),
         "G11": lambda: g11_mc(deberta, load_downstream()[1]),
+        "G12": g12_dataset,
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):
