@@ -280,6 +280,51 @@ __global__ void embed_gather_kernel(const int64_t* ids, const float* E, const fl
   for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) *(f32x4*)(dst + c) = *(const f32x4*)(src + c);
 }
 
+// ---- input side: variable-length fp16 CLIP feature clips -> fixed [B, T, F] fp32 (+ lengths, mask)
+// One block per output row (b, j): 16-byte loads of 8 halves, fp32 stores; slot j of a clip with n > T rows reads row
+// (j*n)/T, a clip with n <= T rows is copied and zero padded (datasets/videotext_dataset.py:27-43).
+__global__ void video_stage_kernel(const _Float16* feats, const int64_t* row_off, const int32_t* n_rows, int T, int F,
+                                   float* out, int64_t* video_len, int64_t* video_mask) {
+  const int b = blockIdx.x / T, j = blockIdx.x % T;
+  const int n = n_rows[b];
+  const int len = n < T ? n : T;
+  if (threadIdx.x == 0) {
+    if (j == 0 && video_len) video_len[b] = len;
+    if (video_mask) video_mask[(long)b * T + j] = j < len ? 1 : 0;
+  }
+  float* dst = out + ((long)b * T + j) * F;
+  if (j >= len) {
+    for (int c = threadIdx.x * 4; c < F; c += blockDim.x * 4) *(f32x4*)(dst + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const long r = n > T ? ((long)j * n) / T : j;
+  const _Float16* src = feats + (row_off[b] + r) * (long)F;
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  for (int c = threadIdx.x * 8; c < F; c += blockDim.x * 8) {
+    const f16x8 h = *(const f16x8*)(src + c);
+    *(f32x4*)(dst + c) = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    *(f32x4*)(dst + c + 4) = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+  }
+}
+
+// ---- masked-LM corruption on the device (util/misc.py:14-56 semantics, counter-based RNG): per token four draws
+// keyed by (seed, 4*index + k): select with probability p unless the id is special / padding; of the selected 80 %
+// become [MASK], half of the rest a uniformly random id, the rest stay; labels = original id where selected else -100.
+__global__ void mask_tokens_kernel(int64_t* ids, int64_t* labels, long n, const int64_t* special, int n_special, float p,
+                                   int64_t mask_id, int64_t vocab, uint64_t seed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  bool sp = false;
+  for (int k = 0; k < n_special; ++k) sp |= (special[k] == id);
+  const float inv = 1.0f / 4294967296.0f;
+  const bool pick = !sp && (float)fbl_hash(seed, 4ull * i) * inv < p;
+  labels[i] = pick ? id : -100;
+  if (!pick) return;
+  if ((float)fbl_hash(seed, 4ull * i + 1) * inv < 0.8f) ids[i] = mask_id;
+  else if ((float)fbl_hash(seed, 4ull * i + 2) * inv < 0.5f) ids[i] = (int64_t)(fbl_hash(seed, 4ull * i + 3) % (uint64_t)vocab);
+}
+
 __global__ void im2col3_kernel(const bf16* x, bf16* out, int B, int S, int H) {
   const int row = blockIdx.x;
   const int s = row % S;
@@ -557,6 +602,27 @@ extern "C" int fbl_embed_gather(const int64_t* ids, const float* E, const float*
   if (B * (T + L) <= 0) return 0;
   hipLaunchKernelGGL(embed_gather_kernel, dim3(B * (T + L)), dim3(128), 0, (hipStream_t)stream, ids, E, vproj, B, T, L,
                      H, out_t);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_video_stage_f16(const void* feats_f16, const int64_t* row_off, const int32_t* n_rows, int B, int T, int F,
+                                   float* out_f32, int64_t* video_len, int64_t* video_mask, void* stream) {
+  if (F % 8 || ((uintptr_t)feats_f16 & 15) || ((uintptr_t)out_f32 & 15)) return FBL_ERR_ALIGN;
+  if (B <= 0 || T <= 0) return 0;
+  hipLaunchKernelGGL(video_stage_kernel, dim3(B * T), dim3(128), 0, (hipStream_t)stream, (const _Float16*)feats_f16, row_off,
+                     n_rows, T, F, out_f32, video_len, video_mask);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_mask_tokens(int64_t* ids, int64_t* labels, int64_t n, const int64_t* special_ids, int n_special,
+                               float mlm_probability, int64_t mask_token_id, int64_t vocab_size, uint64_t seed,
+                               void* stream) {
+  if (n <= 0) return 0;
+  if (vocab_size <= 0 || mlm_probability < 0.f || mlm_probability > 1.f || n_special < 0) return FBL_ERR_ARG;
+  hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, labels,
+                     (long)n, special_ids, n_special, mlm_probability, mask_token_id, vocab_size, seed);
   FBL_CHECK_LAUNCH();
   return 0;
 }

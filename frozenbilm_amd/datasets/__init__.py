@@ -1,1 +1,2 @@
-from .videotext_dataset import VideoText_Dataset, build_videotext_dataset, videotext_collate_fn  # noqa: F401
+from .videotext_dataset import (PackedVideoText_Dataset, VideoText_Dataset, build_videotext_dataset,  # noqa: F401
+                                packed_collate_fn, stage_packed_batch, videotext_collate_fn)

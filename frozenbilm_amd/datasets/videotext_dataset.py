@@ -66,3 +66,35 @@ def build_videotext_dataset(split, args):
         raise NotImplementedError
     return VideoText_Dataset(csv_path=csv_path, features_path=args.webvid_features_path, max_feats=args.max_feats,
                              features_dim=args.features_dim)
+
+
+class PackedVideoText_Dataset(VideoText_Dataset):
+    """Same files, but items keep the raw fp16 clip: the uniform subsample / zero pad / mask are done by one kernel on the
+    GPU (`stage_packed_batch`), so the host only concatenates bytes -- the per-sample Python loop of the reference is the
+    first thing to saturate at the throughput the MI355X path reaches."""
+
+    def __getitem__(self, idx):
+        try:
+            clip = np.load(os.path.join(self.features, str(self.video_id[idx]) + ".mp4.npy"))
+            clip = np.ascontiguousarray(clip, dtype=np.float16).reshape(-1, self.features_dim)
+        except Exception:  # missing video or corrupted feature file
+            clip = np.zeros((0, self.features_dim), dtype=np.float16)
+        return {"clip": torch.from_numpy(clip), "text": self.text[idx]}
+
+
+def packed_collate_fn(batch):
+    n = torch.tensor([len(b["clip"]) for b in batch], dtype=torch.int32)
+    off = torch.zeros(len(batch), dtype=torch.int64)
+    off[1:] = torch.cumsum(n[:-1].long(), 0)
+    clips = [b["clip"] for b in batch if len(b["clip"])]
+    feats = torch.cat(clips, 0) if clips else torch.zeros(1, batch[0]["clip"].shape[1], dtype=torch.float16)
+    return {"feats": feats, "row_off": off, "n_rows": n, "text": [b["text"] for b in batch]}
+
+
+def stage_packed_batch(batch, max_feats, device):
+    """-> the reference batch format, on the device: video fp32 [B,T,F], video_len int64 [B] (+ video_mask [B,T])"""
+    from .. import lib as L
+
+    video, vlen, vmask = L.video_stage_f16(batch["feats"].to(device, non_blocking=True), batch["row_off"].to(device),
+                                           batch["n_rows"].to(device), max_feats)
+    return {"video": video, "video_len": vlen, "video_mask": vmask, "text": batch["text"]}

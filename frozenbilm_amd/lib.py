@@ -35,6 +35,8 @@ SIGNATURES = {
     "fbl_col2im3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dropout_gelu_bwd": (_i, [_vp, _vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_video_stage_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "fbl_mask_tokens": (_i, [_vp, _vp, _l, _vp, _i, _f, _l, _l, _u64, _vp]),
     "fbl_transpose_to_bf16": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp]),
     "fbl_transpose_batched_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fbl_colsum_ws_floats": (_l, [_i]),
@@ -237,6 +239,25 @@ def dropout_gelu_fwd(c, p_drop, seed, out_f32):
 def dropout_gelu_bwd(dy, c, p_drop, seed, out_bf16=None, out_f32=None):
     _chk(load().fbl_dropout_gelu_bwd(_p(dy), _p(c), float(p_drop), int(seed), _p(out_bf16), _p(out_f32), c.numel(),
                                      _stream()), "fbl_dropout_gelu_bwd")
+
+
+def video_stage_f16(feats, row_off, n_rows, T):
+    """packed fp16 clips -> (video fp32 [B,T,F], video_len int64 [B], video_mask int64 [B,T])"""
+    assert feats.dtype == torch.float16 and feats.is_contiguous() and row_off.dtype == torch.int64 and n_rows.dtype == torch.int32
+    B, F_ = n_rows.numel(), feats.shape[1]
+    video = torch.empty(B, T, F_, dtype=torch.float32, device=feats.device)
+    vlen = torch.empty(B, dtype=torch.int64, device=feats.device)
+    vmask = torch.empty(B, T, dtype=torch.int64, device=feats.device)
+    _chk(load().fbl_video_stage_f16(_p(feats), _p(row_off), _p(n_rows), B, T, F_, _p(video), _p(vlen), _p(vmask), _stream()),
+         "fbl_video_stage_f16")
+    return video, vlen, vmask
+
+
+def mask_tokens(ids, labels, special_ids, p, mask_token_id, vocab_size, seed):
+    assert ids.dtype == torch.int64 and labels.dtype == torch.int64 and ids.is_contiguous() and labels.is_contiguous()
+    assert special_ids.dtype == torch.int64
+    _chk(load().fbl_mask_tokens(_p(ids), _p(labels), ids.numel(), _p(special_ids), special_ids.numel(), float(p),
+                                int(mask_token_id), int(vocab_size), int(seed), _stream()), "fbl_mask_tokens")
 
 
 def transpose_batched_bf16(src, src_off, dst, dst_off, rows, cols):

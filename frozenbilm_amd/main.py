@@ -18,13 +18,21 @@ from .util.metrics import MetricLogger
 from .util.misc import adjust_learning_rate, get_mask, mask_tokens
 
 
-def _prepare(batch_dict, tokenizer, device, args):
+def _prepare(batch_dict, tokenizer, device, args, step_seed=0):
+    """main.py:41-58.  Two opt-in device-side shortcuts that leave the reference path untouched: a batch already staged
+    on the GPU by ``datasets.stage_packed_batch`` brings its own ``video_mask``; ``args.device_mask_tokens`` runs the MLM
+    corruption as one kernel on the GPU (same distribution; the default host path reproduces the reference's RNG)."""
     video = batch_dict["video"].to(device)
     video_len = batch_dict["video_len"]
-    video_mask = get_mask(video_len, video.size(1)).to(device)
+    video_mask = batch_dict["video_mask"].to(device) if "video_mask" in batch_dict else get_mask(video_len, video.size(1)).to(device)
     encoded = tokenizer(batch_dict["text"], add_special_tokens=True, max_length=args.max_tokens, padding="longest",
                         truncation=True, return_tensors="pt")
-    inputs, labels = mask_tokens(encoded["input_ids"], tokenizer, mlm_probability=args.mlm_prob)
+    if getattr(args, "device_mask_tokens", False):
+        from .util.misc import mask_tokens_device
+
+        inputs, labels = mask_tokens_device(encoded["input_ids"].to(device), tokenizer, args.mlm_prob, seed=step_seed)
+    else:
+        inputs, labels = mask_tokens(encoded["input_ids"], tokenizer, mlm_probability=args.mlm_prob)
     return dict(video=video, video_mask=video_mask, input_ids=inputs.to(device),
                 attention_mask=encoded["attention_mask"].to(device), labels=labels.to(device))
 
@@ -35,7 +43,7 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
     header = "Epoch: [{}]".format(epoch)
     num_training_steps = int(len(data_loader) * args.epochs)
     for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
-        feed = _prepare(batch_dict, tokenizer, device, args)
+        feed = _prepare(batch_dict, tokenizer, device, args, step_seed=epoch * len(data_loader) + i_batch + 1)
         output = model(**feed)
         loss = output["loss"]
         loss_dict_reduced = dist.reduce_dict({"mlm_loss": loss})

@@ -37,6 +37,35 @@ def mask_tokens(inputs, tokenizer, mlm_probability):
     return inputs, labels
 
 
+def special_token_ids(tokenizer) -> torch.Tensor:
+    """ids `get_special_tokens_mask(..., already_has_special_tokens=True)` flags, plus padding (util/misc.py:27-35)"""
+    ids = set(getattr(tokenizer, "all_special_ids", None) or [])
+    for name in ("pad_token_id", "cls_token_id", "sep_token_id", "mask_token_id", "unk_token_id", "bos_token_id", "eos_token_id"):
+        v = getattr(tokenizer, name, None)
+        if v is not None:
+            ids.add(int(v))
+    return torch.tensor(sorted(ids), dtype=torch.long)
+
+
+def mask_tokens_device(inputs, tokenizer, mlm_probability, seed: int):
+    """`mask_tokens` as one kernel on ids that already live on the GPU (same distribution, counter-based RNG keyed by
+    `seed`; the host version above is the one that reproduces the reference's CPU generator bit for bit).  In place on
+    `inputs` like the reference; returns (inputs, labels)."""
+    from .. import lib as L
+
+    if getattr(tokenizer, "mask_token_id", None) is None:
+        raise ValueError(
+            "This tokenizer does not have a mask token which is necessary for masked language modeling. "
+            "Remove the --mlm flag if you want to use this tokenizer.")
+    if not inputs.is_cuda:
+        raise RuntimeError("mask_tokens_device needs the ids on the GPU (use mask_tokens for host tensors)")
+    inputs = inputs if inputs.is_contiguous() else inputs.contiguous()
+    labels = torch.empty_like(inputs)
+    L.mask_tokens(inputs, labels, special_token_ids(tokenizer).to(inputs.device), mlm_probability, tokenizer.mask_token_id,
+                  len(tokenizer), seed)
+    return inputs, labels
+
+
 def adjust_learning_rate(optimizer, curr_step: int, num_training_steps: int, args):
     """constant, or linear warm-up then linear decay (util/misc.py:59-78); writes param_groups[0]['lr']."""
     warmup = round(args.fraction_warmup_steps * num_training_steps)

@@ -65,6 +65,21 @@ int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb,
 int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H, float* out_t,
                      void* stream);
 
+/* Input side.  feats: packed fp16 [sum n_rows, F] (the per-video CLIP feature files back to back), clip b starts at row
+ * row_off[b] and has n_rows[b] rows.  out[b, j, :] (fp32) = clip row (j*n)/T when n > T, row j when j < n <= T, zeros
+ * otherwise; video_len[b] = min(n, T); video_mask[b, j] = j < video_len[b] (int64, either may be NULL).  F % 8 == 0.
+ * ref: datasets/videotext_dataset.py:23-43 (uniform subsample / zero pad) + util/misc.py:6-11 (get_mask). */
+int fbl_video_stage_f16(const void* feats_f16, const int64_t* row_off, const int32_t* n_rows, int B, int T, int F,
+                        float* out_f32, int64_t* video_len, int64_t* video_mask, void* stream);
+
+/* Masked-LM corruption in place on the device: tokens whose id is not in special_ids[n_special] are selected with
+ * probability mlm_probability; labels = original id where selected, -100 elsewhere; 80 % of the selected become
+ * mask_token_id, 10 % a uniform id in [0, vocab_size), 10 % stay.  Counter-based RNG keyed by (seed, 4*index + draw).
+ * ref: util/misc.py:14-56 (same distribution; the reference draws from torch's CPU generator, so bit parity with it is
+ * provided by the host implementation frozenbilm_amd.util.misc.mask_tokens, not by this kernel). */
+int fbl_mask_tokens(int64_t* ids, int64_t* labels, int64_t n, const int64_t* special_ids, int n_special,
+                    float mlm_probability, int64_t mask_token_id, int64_t vocab_size, uint64_t seed, void* stream);
+
 /* Fused  t = dropout(y) + residual ;  out = LayerNorm(t) * gamma + beta [* rowmask]     (one wave per row).
  *  y: fp32 [N, ldy] or NULL.  dropout: p in [0,1), element (row*H+col) keyed by `seed` (counter-based, regenerated in bwd).
  *  residual, either  r_plain fp32 [N,H]  or the "normalised form" of a previous LayerNorm output:

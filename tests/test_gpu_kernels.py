@@ -621,3 +621,69 @@ def test_attention_dropout_bwd_linearity(L):
     # wrong seed in backward breaks the identity by far more than the tolerance
     dq2, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 100)
     assert (dq2[:, 2 * H:].float() - dqkv[:, 2 * H:].float()).abs().max().item() > 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ input side
+def test_video_stage_matches_reference_dataset(L, golden, tmp_path):
+    """packed fp16 clips -> [B,T,F]: bit-exact against what the REFERENCE's dataset class produced (golden G12)"""
+    from frozenbilm_amd.datasets import PackedVideoText_Dataset, packed_collate_fn, stage_packed_batch
+    from tests.golden.make_goldens import write_feature_fixture
+
+    g = golden("G12_dataset", raw=True)
+    csv_path, feats = write_feature_fixture(str(tmp_path))
+    ds = PackedVideoText_Dataset(csv_path, feats, max_feats=10, features_dim=16)
+    batch = stage_packed_batch(packed_collate_fn([ds[i] for i in range(len(ds))]), 10, DEV)
+    assert torch.equal(batch["video"].cpu(), torch.from_numpy(g["video"]))
+    assert torch.equal(batch["video_len"].cpu(), torch.from_numpy(g["video_len"]))
+    from frozenbilm_amd.util.misc import get_mask
+
+    assert torch.equal(batch["video_mask"].cpu(), get_mask(torch.from_numpy(g["video_len"]), 10))
+    # bench-shaped case: 1024-wide features, many clips
+    gen = torch.Generator().manual_seed(5)
+    n = torch.randint(0, 40, (64,), generator=gen).to(torch.int32)
+    feats = torch.randn(int(n.sum()), 1024, generator=gen).half()
+    off = torch.zeros(64, dtype=torch.int64); off[1:] = torch.cumsum(n[:-1].long(), 0)
+    video, vlen, vmask = L.video_stage_f16(feats.to(DEV), off.to(DEV), n.to(DEV), 10)
+    for b in range(64):
+        nb = int(n[b]); clip = feats[off[b]: off[b] + nb].float()
+        want = torch.zeros(10, 1024)
+        if nb > 10:
+            want = clip[(torch.arange(10) * nb) // 10]
+        else:
+            want[:nb] = clip
+        assert torch.equal(video[b].cpu(), want) and int(vlen[b]) == min(nb, 10)
+
+
+def test_mask_tokens_device(L):
+    from frozenbilm_amd.util.misc import mask_tokens_device
+    from tests.downstream_fixtures import StubTokenizer
+
+    tok = StubTokenizer(30000)
+    gen = torch.Generator().manual_seed(1)
+    B, Lt = 256, 128
+    ids = torch.randint(5, 30000, (B, Lt), generator=gen)
+    ids[:, 0] = tok.cls_token_id
+    tl = torch.randint(8, Lt, (B,), generator=gen)
+    for b in range(B):
+        ids[b, tl[b]] = tok.sep_token_id
+        ids[b, tl[b] + 1:] = tok.pad_token_id
+    orig = ids.clone()
+    x = ids.to(DEV)
+    out, labels = mask_tokens_device(x, tok, 0.15, seed=42)
+    assert out.data_ptr() == x.data_ptr()  # in place, like the reference
+    out, labels = out.cpu(), labels.cpu()
+    special = (orig == tok.pad_token_id) | (orig == tok.cls_token_id) | (orig == tok.sep_token_id)
+    sel = labels != -100
+    assert not (sel & special).any() and torch.equal(labels[sel], orig[sel]) and torch.equal(out[~sel], orig[~sel])
+    n_ok = int((~special).sum()); n_sel = int(sel.sum())
+    assert abs(n_sel / n_ok - 0.15) < 4 * (0.15 * 0.85 / n_ok) ** 0.5
+    masked = sel & (out == tok.mask_token_id)
+    kept = sel & (out == orig)
+    rand = sel & ~masked & ~kept
+    assert abs(int(masked.sum()) / n_sel - 0.8) < 0.02 and abs(int(kept.sum()) / n_sel - 0.1) < 0.015
+    assert abs(int(rand.sum()) / n_sel - 0.1) < 0.015 and int(out[rand].min()) >= 0 and int(out[rand].max()) < 30000
+    # deterministic in the seed, different across seeds
+    y = orig.to(DEV); o2, l2 = mask_tokens_device(y, tok, 0.15, seed=42)
+    assert torch.equal(o2.cpu(), out) and torch.equal(l2.cpu(), labels)
+    z = orig.to(DEV); o3, l3 = mask_tokens_device(z, tok, 0.15, seed=43)
+    assert not torch.equal(l3.cpu(), labels)
