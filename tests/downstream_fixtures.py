@@ -12,6 +12,10 @@ import torch
 
 class StubTokenizer:
     pad_token_id, cls_token_id, sep_token_id, mask_token_id = 0, 1, 2, 4
+    mask_token, _pad_token = "[MASK]", "[PAD]"
+
+    def convert_tokens_to_ids(self, token):
+        return {"[MASK]": self.mask_token_id, "[PAD]": self.pad_token_id}[token]
 
     def __init__(self, vocab_size: int):
         self.vocab_size = vocab_size
@@ -114,6 +118,21 @@ def make_mc_batches(vocab, T, F, n_choices, n_batches, B, seed, min_tok=4, max_t
         out.append(dict(video=video, video_len=vlen, text=text, answer_id=answer_id, qid=[f"m{q + i}" for i in range(B)],
                         type=torch.zeros(B, dtype=torch.long)))
         q += B
+    return out
+
+
+def make_videotext_batches(vocab, T, F, n_batches, B, seed, min_tok=6, max_tok=20):
+    """main.py batches: clip features + plain caption ids (the loop itself applies mask_tokens)"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        video = torch.randn(B, T, F, generator=g).half().float()
+        vlen = torch.randint(1, T + 1, (B,), generator=g)
+        for b in range(B):
+            video[b, vlen[b]:] = 0
+        text = [" ".join(str(t) for t in torch.randint(5, vocab, (int(torch.randint(min_tok, max_tok + 1, (1,), generator=g)),),
+                                                       generator=g).tolist()) for _ in range(B)]
+        out.append(dict(video=video, video_len=vlen, text=text, qid=list(range(B))))
     return out
 
 
