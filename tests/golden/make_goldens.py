@@ -434,7 +434,7 @@ def load_downstream():
     sys.path.insert(0, REF)
     try:
         mods = []
-        for name in ("videoqa", "mc"):
+        for name in ("videoqa", "mc", "main"):
             spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, name + ".py"))
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
@@ -600,6 +600,33 @@ def g12_dataset():
     npz("G12_dataset", video=batch["video"], video_len=batch["video_len"], text=np.array(batch["text"]))
 
 
+def g13_main_loops(deberta, ref_main):
+    """main.py train_one_epoch / evaluate (MLM) of the reference on synthetic caption batches: seeded CPU mask_tokens."""
+    import json
+    from oracle.deberta_oracle import synth_params
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_videotext_batches
+
+    cfg = _tiny_cfg(max_feats=4, vocab_size=300, max_position_embeddings=128)
+    P = synth_params(cfg, seed=21, std=0.08, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    zero_dropout(m)
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videotext_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, 3, 6, seed=31)
+    torch.manual_seed(7)
+    ev = ref_main.evaluate(m, tok, ListLoader(batches), torch.device("cpu"), args)
+    torch.manual_seed(8)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95))
+    before = _trainable_state(m)
+    tr = ref_main.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device("cpu"), 0, args, 0.1)
+    after = _trainable_state(m)
+    out = {"eval_stats": np.array(json.dumps({k: float(v) for k, v in ev.items()})),
+           "train_stats": np.array(json.dumps({k: float(v) for k, v in tr.items()}))}
+    for key in ("deberta.embeddings.linear_video.weight", "deberta.encoder.layer.1.output.adapter.up.weight",
+                "deberta.encoder.layer.0.attention.output.adapter.down.weight", "deberta.encoder.LayerNorm.weight"):
+        out[f"train_delta/{key}"] = after[key] - before[key]
+    npz("G13_main_loops", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -620,6 +647,7 @@ def main():
         "G10": lambda: g10_videoqa(deberta, load_downstream()[0]),
         "G11": lambda: g11_mc(deberta, load_downstream()[1]),
         "G12": g12_dataset,
+        "G13": lambda: g13_main_loops(deberta, load_downstream()[2]),
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):

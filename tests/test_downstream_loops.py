@@ -138,3 +138,33 @@ def test_mc_evaluate_and_train_match_reference(golden):
     for k in DELTA_KEYS:
         d = after[k].detach() - before[k]
         assert cosine(d, torch.as_tensor(g[f"train_delta/{k}"])) > 0.999, k
+
+
+def test_main_loops_match_reference(golden):
+    """main.py:24-153: the product's train_one_epoch / evaluate (host loop, host mask_tokens with the reference's RNG
+    consumption order) driven with the oracle model vs what the reference's own loops returned."""
+    from frozenbilm_amd import main as P_main
+    from tests.downstream_fixtures import make_videotext_batches
+
+    g = golden("G13_main_loops", raw=True)
+    cfg = _tiny_cfg(max_feats=4, vocab_size=300, max_position_embeddings=128)
+    m = OracleModel(cfg, O.synth_params(cfg, seed=21, std=0.08, ln_jitter=0.1))
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videotext_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, 3, 6, seed=31)
+    torch.manual_seed(7)
+    ev = P_main.evaluate(m, tok, ListLoader(batches), torch.device("cpu"), args)
+    ref = _j(g, "eval_stats")
+    assert ev.keys() == ref.keys()
+    for k in ref:
+        assert abs(ev[k] - ref[k]) < 2e-5, (k, ev[k], ref[k])
+    torch.manual_seed(8)
+    before = {k: v.detach().clone() for k, v in m.named_ref_parameters().items()}
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95))
+    tr = P_main.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device("cpu"), 0, args, 0.1)
+    ref = _j(g, "train_stats")
+    assert tr.keys() == ref.keys()
+    for k in ref:
+        assert abs(tr[k] - ref[k]) < 2e-5, (k, tr[k], ref[k])
+    after = m.named_ref_parameters()
+    for k in DELTA_KEYS:
+        assert cosine(after[k].detach() - before[k], torch.as_tensor(g[f"train_delta/{k}"])) > 0.999, k
