@@ -45,6 +45,52 @@ def _worker(rank, world, port, q):
             red.ready(key)
         red.finish()
         ok &= torch.allclose(flat, expect, atol=1e-6)
+        # several backward passes feeding one step (mc.py): nothing leaves before the context closes
+        flat.copy_(mine)
+        with red.accumulate():
+            for _ in range(3):
+                for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
+                    red.ready(key)
+                red.finish()
+                ok &= torch.equal(flat, mine) and not red.pending
+        ok &= torch.allclose(flat, expect, atol=1e-6) and red.last_launched == [(0, n)]
+        # DP equivalence: all-reduced per-rank gradients == single-process gradients of the mean of the
+        # per-rank mean losses, on the oracle model with the flat layout / bucket order of the engine
+        from oracle import deberta_oracle as O
+        from oracle.model_wrapper import OracleModel
+        from frozenbilm_amd.model.config import DebertaV2Config
+        from frozenbilm_amd.model.deberta import flat_order
+        from tests.golden.make_goldens import _tiny_cfg, synth_batch
+
+        cfg = _tiny_cfg(num_hidden_layers=2)
+        P = O.synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1)
+        batch = synth_batch(cfg, B=4, L=12, seed=5)
+
+        def grads(sl):
+            m = OracleModel(_tiny_cfg(num_hidden_layers=2), P)
+            out = m(**{k: v[sl] for k, v in batch.items()})
+            out["loss"].backward()
+            return {k: p.grad for k, p in m.named_ref_parameters().items() if p.requires_grad}, out["loss"].item()
+
+        c = DebertaV2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=2,
+                            num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                            max_position_embeddings=cfg.max_position_embeddings, position_buckets=cfg.position_buckets)
+        mine_g, _ = grads(slice(2 * rank, 2 * rank + 2))
+        order = flat_order(c, list(mine_g))
+        offs, tot = {}, 0
+        for k in order:
+            offs[k] = tot
+            tot += (mine_g[k].numel() + 7) // 8 * 8
+        fg = torch.zeros(tot)
+        for k in order:
+            fg[offs[k]: offs[k] + mine_g[k].numel()] = mine_g[k].flatten()
+        r2 = GradReducer(fg, {"emb": tot}, min_bucket_elems=1)
+        r2.ready("emb"); r2.finish()
+        g0, _ = grads(slice(0, 2)); g1, _ = grads(slice(2, 4))
+        for k in order:
+            want = 0.5 * (g0[k] + g1[k])
+            got = fg[offs[k]: offs[k] + want.numel()].view_as(want)
+            ok &= torch.allclose(got, want, rtol=1e-5, atol=1e-7)
         rd = D.reduce_dict({"b": torch.tensor(float(rank)), "a": torch.tensor(10.0 + rank)})
         ok &= abs(rd["a"].item() - 10.5) < 1e-6 and abs(rd["b"].item() - 0.5) < 1e-6
         gathered = D.all_gather({"rank": rank, "payload": list(range(rank + 3))})
