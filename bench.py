@@ -189,8 +189,9 @@ def measure_gemm_roofline(L, step_fn):
         B2 = B[0] if B.dim() == 3 else B
         M = kw.get("M") or A2.shape[0]
         N = kw.get("N") or B2.shape[0]
+        K = kw.get("K") or A2.shape[1]  # (k-blocked A operands pass the true contraction length explicitly)
         nb = A.shape[0] if A.dim() == 3 else 1
-        recs.append((s, e, 2.0 * M * N * A2.shape[1] * nb, (M, N, A2.shape[1], nb)))
+        recs.append((s, e, 2.0 * M * N * K * nb, (M, N, K, nb)))
 
     lib.gemm = timed
     try:

@@ -12,6 +12,7 @@ on the fly, so the fp32 normalised tensor is never written to HBM, and ``t`` dou
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -81,10 +82,10 @@ class Engine:
         self.sk_ws = torch.empty(16 << 20, dtype=F32, device=dev)  # 64 MiB split-K partials (main stream)
         # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
         # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
-        self.side = torch.cuda.Stream(device=dev)
+        self.side = torch.cuda.Stream(device=dev)  # (stream priorities were measured: no effect on the interference)
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
-        self.use_side_stream = True
+        self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
 
     # ------------------------------------------------------------------ parameter plumbing
     def _build_flat(self):
