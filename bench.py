@@ -59,6 +59,9 @@ def synth_batch(B, T, F, L, V, seed, device):
                                                labels=labels).items()}
 
 
+PREWARM_STEPS = 12
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +121,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock / power-state ramp: a box that has just been handed over can sit in a low-power state for the first second of
+    # load (one round-1 run measured 2x slower end to end for that reason), so a fixed untimed pre-warm precedes the W
+    # warm-up steps the contract asks for
+    for _ in range(PREWARM_STEPS):
+        step()
     for _ in range(args.warmup):
         loss = step()
     sync()
@@ -163,7 +171,7 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "head": "full fp32 logits [B,S,128100] in forward; CE + head backward on labelled rows",
                        "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted"},
-            "loss": loss_value, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "prewarm_steps": PREWARM_STEPS, "loss": loss_value, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "algorithmic_tflops_per_step": step_flops / 1e12,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build,
         }
