@@ -467,6 +467,8 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16* src,
 }
 
 // ---- cross entropy
+// One block per row; a single pass over the 128100 logits with 16-byte loads: every thread keeps an online
+// (max, sum exp) pair that is merged across the block at the end.
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, long ldv, const int64_t* labels, int N, int V,
                                                      float* row_lse, float* loss_sum_cnt) {
   const int row = blockIdx.x;
@@ -475,22 +477,46 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, long l
     if (threadIdx.x == 0) row_lse[row] = 0.f;
     return;
   }
-  __shared__ float red[4];
+  __shared__ float red_m[4], red_s[4];
   const float* x = logits + (long)row * ldv;
-  float m = -INFINITY;
-  for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float s = 0.f;
-  for (int i = threadIdx.x; i < V; i += 256) s += __expf(x[i] - m);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  float m = -INFINITY, s = 0.f;
+  auto push = [&](float v) {
+    if (v > m) {
+      s = s * __expf(m - v) + 1.f;  // (m = -inf: s is 0)
+      m = v;
+    } else {
+      s += __expf(v - m);
+    }
+  };
+  const bool vec = ((ldv & 3) == 0) && (((uintptr_t)logits & 15) == 0);
+  const int V4 = vec ? (V >> 2) : 0;
+  for (int i = threadIdx.x; i < V4; i += 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (vm > m) {
+      s *= __expf(m - vm);
+      m = vm;
+    }
+    s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+  }
+  for (int i = 4 * V4 + threadIdx.x; i < V; i += 256) push(x[i]);
+  // merge (m, s) pairs: wave, then block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red_m[threadIdx.x >> 6] = m;
+    red_s[threadIdx.x >> 6] = s;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float lse = m + logf(red[0] + red[1] + red[2] + red[3]);
+    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])), S = 0.f;
+    for (int k = 0; k < 4; ++k) S += (red_m[k] == -INFINITY) ? 0.f : red_s[k] * __expf(red_m[k] - M);
+    const float lse = M + logf(S);
     row_lse[row] = lse;
     atomicAdd(loss_sum_cnt, lse - x[lab]);
     atomicAdd(loss_sum_cnt + 1, 1.0f);
@@ -501,12 +527,21 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, l
                                                           const float* loss_sum_cnt, float gscale, bf16* out) {
   const int r = blockIdx.x;
   const int row = rows[r];
-  const int64_t lab = labels[row];
+  const int lab = (int)labels[row];
   const float lse = row_lse[row];
   const float sc = gscale / fmaxf(loss_sum_cnt[1], 1.0f);
   const float* x = logits + (long)row * ldv;
   bf16* o = out + (long)r * Vp;
-  for (int i = threadIdx.x; i < Vp; i += 256) {
+  const bool vec = ((ldv & 3) == 0) && ((Vp & 3) == 0) && (((uintptr_t)logits & 15) == 0) && (((uintptr_t)out & 7) == 0);
+  const int V4 = vec ? (V >> 2) : 0;
+  for (int i = threadIdx.x; i < V4; i += 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (__expf(v[e] - lse) - ((4 * i + e) == lab ? 1.f : 0.f)) * sc;
+    *(bf16x4*)(o + 4 * i) = (bf16x4){f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
+  }
+  for (int i = 4 * V4 + threadIdx.x; i < Vp; i += 256) {
     float g = 0.f;
     if (i < V) g = (__expf(x[i] - lse) - (i == lab ? 1.f : 0.f)) * sc;
     o[i] = f2bf(g);
