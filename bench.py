@@ -149,10 +149,12 @@ def main():
     whole_step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank replays the instrumented steps (they contain the gradient collectives); rank 0 reports its own
         roofline = measure_gemm_roofline(L, step)
         roofline["whole_step_algorithmic_tflops"] = whole_step_tflops
         roofline["whole_step_frac_of_peak"] = whole_step_tflops / PEAK_BF16_TFLOPS
+        sync()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
