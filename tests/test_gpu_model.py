@@ -235,3 +235,42 @@ def test_xlarge_golden(golden):
     agree = (lg.argmax(-1).cpu() == g["argmax"]).float().mean().item()
     print("argmax agreement", agree)
     assert agree > 0.93
+
+
+def test_max_length_s512_forward_backward_vs_oracle():
+    """BASELINE config 5 regime: S = T + L = 512 exactly (L = 502 with ASR context), so every log bucket of the relative-
+    position map and all 8 key tiles are exercised; 2-way answer head; forward + gradients vs the fp32 oracle."""
+    cfg = _tiny_cfg(n_ans=2, num_hidden_layers=2)
+    P = O.synth_params(cfg, seed=55, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    g = torch.Generator().manual_seed(12)
+    a2tok = torch.randint(5, cfg.vocab_size, (2, 3), generator=g)
+    m.set_answer_embeddings(a2tok.to(DEV))
+    Po = {k: v.clone() for k, v in P.items()}
+    Po["answer_embeddings.weight"] = O.answer_embeddings(a2tok, P, cfg)
+    batch = synth_batch(cfg, B=3, L=502, seed=13)
+    batch["attention_mask"][0] = 1  # one sample at the full length
+    batch["input_ids"][0] = torch.randint(5, cfg.vocab_size, (502,), generator=g)
+    batch.pop("labels")
+    for k, v in Po.items():
+        v.requires_grad_(O.is_trainable(k))
+    ref = O.forward(Po, cfg, **batch)
+    out = m(**to_dev(batch))
+    assert out.logits.shape == (3, 512, 2)
+    valid = torch.cat([batch["video_mask"], batch["attention_mask"]], 1).bool()
+    err = (out.logits.float().cpu() - ref["logits"])[valid].abs().max().item()
+    assert err < 5e-2, err
+    # mc.py-style score on one row per sample, back-propagated through the logits
+    rows = torch.tensor([300, 40, 17])
+    pick = lambda lg: lg[torch.arange(3), rows].softmax(-1)[:, 0]
+    tgt = torch.tensor([1.0, 0.0, 1.0])
+    torch.nn.functional.binary_cross_entropy(pick(ref["logits"]), tgt).backward()
+    torch.nn.functional.binary_cross_entropy(pick(out.logits), tgt.to(DEV)).backward()
+    bad = []
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            r = Po[name].grad
+            fro = (p.grad.float().cpu() - r).norm().item() / max(r.norm().item(), 1e-12)
+            if fro > (0.25 if "adapter.down" in name else 6e-2):
+                bad.append((name, round(fro, 4)))
+    assert not bad, bad[:8]
