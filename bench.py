@@ -130,8 +130,13 @@ def main():
         loss = step()
     sync()
     t0 = time.time()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_marks = []
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
+        host_marks.append(time.time())
     t_host = time.time() - t0  # host time to ENQUEUE the steps (the loop only blocks on the per-step label-count sync)
     sync()
     dt = time.time() - t0
@@ -140,6 +145,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     loss_value = float(loss.item())
+    step_ms_gpu = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]  # diagnostic: per-step GPU timeline
+    step_ms_host = [round((b - a) * 1e3, 2) for a, b in zip([t0] + host_marks[:-1], host_marks)]
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
@@ -173,7 +180,8 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "head": "full fp32 logits [B,S,128100] in forward; CE + head backward on labelled rows",
                        "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted"},
-            "prewarm_steps": PREWARM_STEPS, "loss": loss_value, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
+            "loss": loss_value, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "algorithmic_tflops_per_step": step_flops / 1e12,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build,
         }

@@ -722,16 +722,7 @@ class Engine:
         self.attach_grads()
         reducer = self.reducer
 
-        class _Ready:  # a bucket may only leave once the side-stream dW kernels that fill it have finished
-            def ready(_, key):
-                if getattr(run, "side_used", False):
-                    torch.cuda.current_stream().wait_stream(self.side)
-                reducer.ready(key)
-
-            def finish(_):
-                reducer.finish()
-
-        red = _Ready() if reducer is not None else None
+        red = _Ready(self, run, reducer) if reducer is not None else None
         dq = torch.zeros(N, H, dtype=F32, device=dev)
         Vout = run.Vout
         Vp = _ru(Vout, 64)
@@ -826,6 +817,25 @@ class Engine:
         dcol = torch.empty(N, 3 * H, dtype=F32, device=dev)
         L.gemm(dc, self.WcT, rowscale=run.mask_f, out_f32=dcol)
         return dt, dcol
+
+
+class _Ready:
+    """Reducer front end used by Engine.backward: a bucket may only leave once the side-stream dW kernels that fill it
+    have finished.  (Module level on purpose: a class created per call is only reclaimed by the cyclic GC, and its
+    closure would keep the whole `run` -- gigabytes of saved activations -- alive until then.)"""
+
+    __slots__ = ("eng", "run", "reducer")
+
+    def __init__(self, eng, run, reducer):
+        self.eng, self.run, self.reducer = eng, run, reducer
+
+    def ready(self, key):
+        if getattr(self.run, "side_used", False):
+            torch.cuda.current_stream().wait_stream(self.eng.side)
+        self.reducer.ready(key)
+
+    def finish(self):
+        self.reducer.finish()
 
 
 @dataclass
