@@ -225,6 +225,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
 #pragma unroll
   for (int half = 0; half < (MI + 3) / 4; ++half) {  // the wave tile leaves in slabs of (up to) 64 rows
     const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
+    // The aux operand of the slab is requested BEFORE the accumulators make their LDS round trip: issued inside the
+    // row loop, every iteration exposed a full global-load latency (32 dependent loads per wave on a 256x256 tile).
+    constexpr bool AUX_F32 = (AUX == FBL_AUX_ADD_F32);
+    const bool aux_fast = (AUX != FBL_AUX_NONE) && !SPLITK && full && ((g.ld_aux & 3) == 0);
+    f32x4 xa32[AUX_F32 ? 16 : 1];
+    bf16x4 xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? 16 : 1];
+    if (AUX != FBL_AUX_NONE && aux_fast) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = min(m0 + wm * WROWS + half * 64 + it * 4 + er, g.M - 1);
+        const long ao = xbase + (long)m * g.ld_aux + n4;
+        if (it < cnt * 4) {
+          if (AUX_F32) xa32[it] = *(const f32x4*)((const float*)g.aux + ao);
+          else xa16[it] = *(const bf16x4*)((const bf16*)g.aux + ao);
+        }
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
       if (half * 4 + mi < MI) {
@@ -233,8 +250,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
           *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
       }
     if (n4 < g.N) {
-#pragma unroll 4
-    for (int it = 0; it < cnt * 4; ++it) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (it >= cnt * 4) break;
       const int row = it * 4 + er;
       const int m = m0 + wm * WROWS + half * 64 + row;
       if (m >= g.M) continue;
@@ -263,15 +281,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
         const long ao = xbase + (long)m * g.ld_aux + n4;
         float x[4] = {0.f, 0.f, 0.f, 0.f};
         if (AUX == FBL_AUX_ADD_F32) {
-          if (full && (g.ld_aux & 3) == 0) {
-            const f32x4 t = *(const f32x4*)((const float*)g.aux + ao);
+          if (aux_fast) {
+            const f32x4 t = xa32[AUX_F32 ? it : 0];
             x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
           } else {
             for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = ((const float*)g.aux)[ao + r];
           }
         } else {
-          if (full && (g.ld_aux & 3) == 0) {
-            const bf16x4 t = *(const bf16x4*)((const bf16*)g.aux + ao);
+          if (aux_fast) {
+            const bf16x4 t = xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? it : 0];
             x[0] = bf2f(t[0]); x[1] = bf2f(t[1]); x[2] = bf2f(t[2]); x[3] = bf2f(t[3]);
           } else {
             for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = bf2f(((const bf16*)g.aux)[ao + r]);
