@@ -421,13 +421,28 @@ __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, 
   const int nq = Nw >> 2;
   if (q >= (long)M * nq) return;
   const int m = (int)(q / nq), n4 = (int)(q % nq) * 4;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* p = ws + ((long)b * splitk * M + m) * Nw + n4;
-  for (int k = 0; k < splitk; ++k) acc += *(const f32x4*)(p + (long)k * M * Nw);
+  const long ks = (long)M * Nw;
   float* o = out + b * sC + (long)m * ldc + n4;
+  const bool vec = (n4 + 3 < N) && ((ldc & 3) == 0) && ((sC & 3) == 0);
+  f32x4 acc = vec ? *(const f32x4*)o : (f32x4){0.f, 0.f, 0.f, 0.f};
+  // partials are summed in index order (deterministic); 8 independent loads in flight per thread
+  int k = 0;
+  for (; k + 8 <= splitk; k += 8) {
+    f32x4 t[8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (n4 + r < N) o[r] += acc[r];
+    for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(p + (k + u) * ks);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += t[u];
+  }
+  for (; k < splitk; ++k) acc += *(const f32x4*)(p + k * ks);
+  if (vec) {
+    *(f32x4*)o = acc;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n4 + r < N) o[r] += acc[r];
+  }
 }
 
 }  // namespace
