@@ -16,6 +16,9 @@ from . import lib as L
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+POISON_GT = False
+
+
 def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     """defer_pos=True: skip the position-table GEMMs and return the state `pos_table_grads` needs (the caller runs it
     off the critical path); otherwise dpqk [span2, 2H] (bf16, [dPQ|dPK]) is filled here."""
@@ -55,12 +58,15 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
     G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+    if POISON_GT:  # test switch: blocks the shear kernel legitimately leaves unwritten must never be read
+        G1T.fill_(float("nan"))
+        G2T.fill_(float("nan"))
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
                             lin=lin)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
                             rcnt=rcnt, lin=lin)
     del dS, dST
-    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp)
+    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen)
     if defer_pos:
         return state
     dpos = pos_table_grads(eng, state, getattr(eng, "sk_ws", None))
@@ -82,6 +88,9 @@ def pos_table_grads(eng, st, ws):
     kblk = rcnt * 32  # elements between consecutive 32-wide k blocks of G^T
     a1 = torch.as_strided(G1T, (nh, rcnt, 32), (G1T.stride(0), 32, 1))
     a2 = torch.as_strided(G2T, (nh, rcnt, 32), (G2T.stride(0), 32, 1))
-    L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
-    L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk)
+    # G^T blocks beyond a sample's last valid position are all zero: the shear kernel does not write them and the GEMM
+    # skips those k-steps (roughly half of K on ragged batches)
+    ks = dict(kskip_len=st["klen"], kskip_steps=Sp // 64) if st.get("klen") is not None else {}
+    L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
+    L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
     return dpos

@@ -337,7 +337,10 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int kl = a.klen ? min(a.klen[b], S) : S;
   if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
-    for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
+    // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
+    // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
+    if ((blockIdx.x & 1) && (r0 - 32 < kl))
+      for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
     if (row < S) {
       bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll

@@ -49,6 +49,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
   int Nw;
+  const int32_t* kskip_len;  // optional: K is made of samples of kskip_steps k-steps; step j of sample b is all zero when 64*j >= kskip_len[b]
+  int kskip_steps;
   long a_kblk;  // 0: A rows are K-contiguous.  >0: A is stored in 32-wide k blocks: A[m][k] at m*lda + (k/32)*a_kblk + k%32
 };
 
@@ -61,7 +63,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // MI_ = 7 with NW = 8 a 224x256 tile for shapes whose 256x256 grid leaves CUs idle (8512 rows = 38 x 224 exactly:
 // 228 tiles on 256 CUs for N = 1536 instead of 204 bigger ones).  LDS keeps the 32*NW-row A image; the unused rows are
 // simply not fetched.
-template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0, int MI_ = NW>
+template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0, int MI_ = NW, bool KSKIP = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   using Cfg = TileCfg<NW>;
   constexpr int BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
@@ -178,6 +180,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
       mfma_block(af1, bf1);
     }
     __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
+  } else if constexpr (KSKIP) {
+    // K-steps whose operand block is known to be all zero (rows beyond a sample's last valid position in the G^T
+    // operand of the position-table gradients) are neither fetched nor multiplied
+    auto next_valid = [&](int kt) {
+      while (kt < kt1) {
+        const int b = kt / g.kskip_steps;
+        if ((kt - b * g.kskip_steps) * BK < g.kskip_len[b]) break;
+        ++kt;
+      }
+      return kt;
+    };
+    int kt = next_valid(kt0);
+    if (kt < kt1) {
+      issue(kt, 0);
+      __syncthreads();
+      int stage = 0;
+      while (kt < kt1) {
+        const int nxt = next_valid(kt + 1);
+        if (nxt < kt1) issue(nxt, stage ^ 1);
+        const char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 af[MI], bfg[4];
+          read_frags(base, s, af, bfg);
+          mfma_block(af, bfg);
+        }
+        __syncthreads();
+        kt = nxt;
+        stage ^= 1;
+      }
+    }
   } else {
   issue(kt0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
@@ -452,7 +485,8 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
                                 int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                                 int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
-                                int64_t splitk_ws_floats, int64_t a_kblock_stride, void* stream) {
+                                int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
+                                void* stream) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
@@ -480,6 +514,9 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.ws = accumulate ? splitk_ws : nullptr;
   g.Nw = Nw;
   g.a_kblk = a_kblock_stride;
+  g.kskip_len = kskip_len;
+  g.kskip_steps = kskip_steps;
+  if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
   const bool big = !force_small && !accumulate && batch == 1 && M >= 2048 && N >= 1024 &&
@@ -503,7 +540,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
       const int m_big = tm_big * 256;
       if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
         int rc = fbl_gemm_bf16_nt(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
-                                  out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, stream);
+                                  out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0, stream);
         if (rc) return rc;
         const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
         return fbl_gemm_bf16_nt((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
@@ -512,7 +549,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
                                 out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
                                 out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
-                                1, nullptr, -2, a_kblock_stride, stream);
+                                1, nullptr, -2, a_kblock_stride, nullptr, 0, stream);
       }
     }
   }
@@ -578,7 +615,17 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     FBL_CHECK_LAUNCH();
     return 0;
   }
-  if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
+  if (accumulate && kskip_len) {
+    static bool attr_ks = false;
+    auto kfn = gemm_bf16_nt_kernel<4, FBL_ACT_NONE, FBL_AUX_NONE, true, 0, 4, true>;
+    constexpr int smem_bytes = TileCfg<4>::SMEM_BYTES;
+    if (!attr_ks) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+      if (e != hipSuccess) return (int)e;
+      attr_ks = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), smem_bytes, (hipStream_t)stream, g);
+  } else if (accumulate) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_NONE, true);
   else if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_RELU && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_RELU, FBL_AUX_NONE, false);
   else if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) FBL_GEMM_LAUNCH(FBL_ACT_GELU_GRAD, FBL_AUX_NONE, false);

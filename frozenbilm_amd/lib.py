@@ -23,7 +23,7 @@ _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
-                              _l, _l, _l, _i, _vp, _l, _l, _vp]),
+                              _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -111,7 +111,7 @@ def _rows2d(t: torch.Tensor, name: str):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, aux_kind=AUX_NONE, out_f32=None,
-         out_bf16=None, out_pre=None, splitk=1, M=None, N=None, ws=None, K=None, a_kblock=0):
+         out_bf16=None, out_pre=None, splitk=1, M=None, N=None, ws=None, K=None, a_kblock=0, kskip_len=None, kskip_steps=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B: bf16 2-D views (or 3-D for strided batch)."""
     _req(A, torch.bfloat16, "A")
     _req(B, torch.bfloat16, "B")
@@ -158,7 +158,8 @@ def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, a
         _req(rowscale, torch.float32, "rowscale")
     code = load().fbl_gemm_bf16_nt(_p(A), lda, _p(B), ldb, M, N, K, _p(bias), _p(rowscale), float(alpha), act, aux_kind,
                                    _p(aux), ld_aux, _p(out_f32), _p(out_bf16), _p(out_pre), ldc or 0, batch, sA, sB, sC,
-                                   sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), int(a_kblock), _stream())
+                                   sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), int(a_kblock),
+                                   _p(kskip_len), int(kskip_steps), _stream())
     _chk(code, "fbl_gemm_bf16_nt")
 
 

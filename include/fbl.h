@@ -43,6 +43,9 @@ int fbl_abi_version(void);
  * batch > 1: strided batch (strides in elements).  splitk > 1: ACCUMULATE mode, out_f32 += A.B^T with the K range
  * split over `splitk` workgroup sets; partial tiles go to `splitk_ws` (>= batch*splitk*M*roundup(N,4) floats) and are
  * folded deterministically by a second tiny kernel; with splitk_ws == NULL (or too small) they are atomicAdd-ed.
+ * kskip_len != NULL (split-K / accumulate mode only): K consists of samples of kskip_steps 64-wide k-steps each and step j of
+ * sample b is known to be all zero in A when 64*j >= kskip_len[b] (int32, device): such steps are neither read nor
+ * multiplied -- the rows of G^T beyond a sample's last valid position (fbl_disent_attn_bwd_shear leaves them unwritten).
  * a_kblock_stride > 0: A is k-blocked, A[m][k] lives at m*lda + (k/32)*a_kblock_stride + k%32 (the G^T layout written
  * by fbl_disent_attn_bwd_shear, lda = 32); 0 = plain K-contiguous rows.
  * ref: every nn.Linear on the path -- model/deberta.py:255,311,329,757-765,847-853,994,1545,1550;
@@ -51,7 +54,8 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      const float* rowscale, float alpha, int act, int aux_kind, const void* aux, int64_t ld_aux,
                      float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
-                     float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, void* stream);
+                     float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len,
+                     int kskip_steps, void* stream);
 
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
@@ -172,7 +176,8 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  *                              workgroup writes one contiguous block: GT[h][b][t][r][32] with t = row/32, r in
  *                              [0, gt_rcnt) standing for table row gt_rmin + r (the range of relidx; others are 0).
  *                              lin_span: |i-j| < lin_span => relidx is injective there (identity buckets, = position_buckets/2;
- *                              0 if unknown): those entries are scattered with plain LDS stores instead of atomics. */
+ *                              0 if unknown): those entries are scattered with plain LDS stores instead of atomics.  * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
+ * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,

@@ -514,11 +514,16 @@ def test_attention_fwd_dropout_rate(L):
     assert ctx.float().std().item() > 1e-3  # not all ones: dropout really dropped something
 
 
-@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2)])
+@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1)])
 def test_attention_bwd(L, B, S, nh):
     from frozenbilm_amd.attn_bwd import disent_attn_bwd
 
     qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=20 + S)
+    if B == 3:  # short samples: whole 64-row steps of G^T beyond klen stay unwritten and must be skipped downstream
+        mask[1, 70:] = 0
+        mask[2, 33:] = 0
+    if S == 512:
+        mask[1, 200:] = 0
     qkv = (qkv.float() * 0.5).to(BF16)
     pqk = (pqk.float() * 0.5).to(BF16)
     ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh)
@@ -542,6 +547,8 @@ def test_attention_bwd(L, B, S, nh):
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
     run.klen = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
+    import frozenbilm_amd.attn_bwd as AB
+    AB.POISON_GT = True  # unwritten G^T blocks hold NaN: the position-table GEMMs must skip exactly those
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 0
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
     dpqk = torch.zeros(pqk.shape[0], 2 * H, dtype=BF16, device=DEV)
