@@ -200,11 +200,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
         const int nxt = next_valid(kt + 1);
         if (nxt < kt1) issue(nxt, stage ^ 1);
         const char* base = smem + stage * STAGE_BYTES;
+        if (n0 + wn * 64 < g.N) {  // (N = 64 here: the second column of waves only helps with the staging)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8 af[MI], bfg[4];
-          read_frags(base, s, af, bfg);
-          mfma_block(af, bfg);
+          for (int s = 0; s < 2; ++s) {
+            bf16x8 af[MI], bfg[4];
+            read_frags(base, s, af, bfg);
+            mfma_block(af, bfg);
+          }
         }
         __syncthreads();
         kt = nxt;
