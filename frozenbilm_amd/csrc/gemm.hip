@@ -360,8 +360,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
 // "TN" variant for the trainable-weight gradients:  C[M,N] += sum_k A[k,m] * B[k,n]   (A [K,M], B [K,N] row-major, the
 // contraction runs over ROWS: dW = X^T . dY without materialising X^T / dY^T in HBM).  128x128x64 tile, 4 waves.
 // Tiles are staged row-major in LDS (coalesced 16-byte global loads, next tile prefetched into registers) and the
-// MFMA fragments -- 8 consecutive k for one m -- are gathered with 8 ds_read_u16 each (conflict-free: the 16 lanes of
-// a group read 16 consecutive columns).  LDS-read bound at ~1/2 the NT rate, which is fine: these GEMMs are ~5 GFLOP.
+// MFMA fragments -- 8 consecutive k for one m -- come out of the row-major image through the hardware transpose read
+// ds_read_b64_tr_b16 (two per fragment).
 // Always split-K with a workspace fold (accumulates into C).
 struct GemmTnArgs {
   const bf16* A; const bf16* B; long lda, ldb;
@@ -369,6 +369,10 @@ struct GemmTnArgs {
   float* ws; int Nw;  // partials [splitk][M][Nw]
   int splitk, tiles_m, tiles_n;
 };
+typedef __attribute__((ext_vector_type(4))) short tr16x4;
+__device__ __forceinline__ tr16x4 lds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr16x4*)p);
+}
 constexpr int TN_LD = 136;  // bf16 row stride of the staged [64 k][128 cols] tiles (272 B: 16B-aligned rows)
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmTnArgs g) {
@@ -420,12 +424,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmTnArgs g) {
       bf16x8 af[4], bfg[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int kr = (s * 32 + fg * 8 + e) * TN_LD;
-          af[i][e] = sA[kr + wm * 64 + i * 16 + frow];
-          bfg[i][e] = sB[kr + wn * 64 + i * 16 + frow];
-        }
+        // ds_read_b64_tr_b16: the 16 lanes of a group hand in the 4x16 block (rows k..k+3, 16 columns) as 16 x 8 bytes
+        // and each lane gets its own column back -- 4 consecutive k of one m: two reads per MFMA fragment instead
+        // of eight ds_read_u16 (semantics probed on hardware: tools/probe/tr16_probe.hip)
+        const int kr = (s * 32 + fg * 8 + (frow >> 2)) * TN_LD + (frow & 3) * 4;
+        const tr16x4 a0 = lds_tr16(sA + kr + wm * 64 + i * 16), a1 = lds_tr16(sA + kr + 4 * TN_LD + wm * 64 + i * 16);
+        const tr16x4 b0 = lds_tr16(sB + kr + wn * 64 + i * 16), b1 = lds_tr16(sB + kr + 4 * TN_LD + wn * 64 + i * 16);
+        union { tr16x4 h[2]; bf16x8 v; } ua, ub;
+        ua.h[0] = a0; ua.h[1] = a1; ub.h[0] = b0; ub.h[1] = b1;
+        af[i] = ua.v;
+        bfg[i] = ub.v;
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
