@@ -32,6 +32,14 @@ __device__ __forceinline__ f16x4 to_f16x4(f32x4 v) {
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// ds_read_b64_tr_b16: the 16 lanes of a group each pass the address of 4 contiguous 16-bit elements -- together a
+// [4 rows][16 columns] block of a row-major LDS image (lane i: row i/4, columns (i%4)*4..+3) -- and lane i receives
+// column i of that block, i.e. 4 consecutive rows of one column (lane mapping probed in tools/probe/tr16_probe.hip).
+typedef __attribute__((ext_vector_type(4))) short tr16x4;
+__device__ __forceinline__ tr16x4 lds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr16x4*)p);
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 
 // Relative-index table padded to the 64-tile grid: idxp[t] = relidx[clamp(t - (Sp - S), 0, 2S-2)] with t = i - j + Sp - 1,

@@ -20,9 +20,9 @@ namespace {
 using namespace attn;
 
 struct AttnArgs {
-  const bf16* q; const bf16* k; const bf16* vt; const bf16* pk; const bf16* pq;
+  const bf16* q; const bf16* k; const bf16* v; const bf16* pk; const bf16* pq;
   long ldq, ldk, ldp;
-  long v_sh, v_sb, v_sd;
+  long ldv;
   const int16_t* relidx;
   const int32_t* mask;
   const int32_t* klen;  // [B] last valid position + 1 (tiles beyond it are exactly zero and skipped) or null
@@ -35,7 +35,7 @@ struct AttnArgs {
 };
 
 constexpr int SM_KS = 0;                        // [64][64] bf16 swizzled
-constexpr int SM_VT = SM_KS + 8192;             // [64 d][72] bf16
+constexpr int SM_VT = SM_KS + 8192;             // V tile, row-major [64 keys][72] bf16 (read transposed by ds_read_b64_tr_b16)
 constexpr int SM_PK = SM_VT + 64 * LDV * 2;     // [128][64] bf16 swizzled
 constexpr int SM_PQ = SM_PK + 16384;
 constexpr int SM_T1 = SM_PQ + 16384;            // [4 waves][16][LT] fp16
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const int row = srow + t * 32;
       const int j = min(j0 + row, S - 1);
       R.k[t] = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + sch * 8);
-      R.v[t] = *(const bf16x8*)(a.vt + h * a.v_sh + b * a.v_sb + row * a.v_sd + j0 + sch * 8);
+      R.v[t] = *(const bf16x8*)(a.v + ((long)b * S + j) * a.ldv + h * 64 + sch * 8);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -223,15 +223,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const char* vrow = smem + SM_VT + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 4) * 2;
-        const bf16x4 v0 = *(const bf16x4*)vrow;
-        const bf16x4 v1 = *(const bf16x4*)(vrow + 32);
-        bf16x8 vf;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vf[e] = v0[e];
-          vf[4 + e] = v1[e];
-        }
+        // V^T fragment (row d = dt*16 + c, keys kk*32 + g*4 + {0..3} and +16) straight from the row-major V tile:
+        // the 16 lanes of a group present a [4 keys][16 d] block and the transpose read hands each lane its column
+        const bf16* vblk = (const bf16*)(smem + SM_VT) + (kk * 32 + g * 4 + (c >> 2)) * LDV + dt * 16 + (c & 3) * 4;
+        union { tr16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = lds_tr16(vblk);
+        u.h[1] = lds_tr16(vblk + 16 * LDV);
+        const bf16x8 vf = u.v;
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
       }
     }
@@ -254,17 +252,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
-                                   int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp,
+extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                   const void* pk, const void* pq, int64_t ldp,
                                    const int16_t* relidx, const int32_t* mask, const int32_t* klen, float scale,
                                    float p_drop, uint64_t seed,
                                    void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
                                    void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
-  if ((ldq % 8) || (ldk % 8) || (ldp % 8) || (ldo % 4) || (v_sh % 8) || (v_sb % 8) || (v_sd % 8)) return FBL_ERR_ALIGN;
+  if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldp % 8) || (ldo % 4)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, v_sh,
-             v_sb, v_sd, relidx, mask, klen, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL);

@@ -379,12 +379,10 @@ class Engine:
             L.gemm(q.full, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
             L.gemm(kv.full, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
         pq, pk = qkv[N:, :H], qkv[N:, H:2 * H]
-        vt = torch.empty(B, nh, 64, Sp, dtype=BF16, device=dev)
-        L.head_transpose(qkv[:N, 2 * H:], vt, B, S, Sp, nh)
         ctx = torch.empty(N, H, dtype=BF16, device=dev)
         lse = torch.empty(B, nh, S, dtype=F32, device=dev)
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
-        L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], vt, pk, pq, self.relidx(S), run.mask_i32,
+        L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], qkv[:N, 2 * H:], pk, pq, self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
                           seed=sv.seed_att, klen=run.klen)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
@@ -412,7 +410,7 @@ class Engine:
         out, sv.seed_ln2 = self._ln(run, p + ".output.LayerNorm", y=y2, resid=Stream(bf16=a.bf16, norm=a.norm), N=N,
                                     p_drop=run.p_hid, tail=self.span2)
         if run.save:
-            sv.qkv, sv.vt, sv.pqk, sv.ctx, sv.lse = qkv[:N], vt, qkv[N:, : 2 * H], ctx, lse
+            sv.qkv, sv.pqk, sv.ctx, sv.lse = qkv[:N], qkv[N:, : 2 * H], ctx, lse
             sv.ob, sv.z1, sv.ln1 = ob, z1, a.norm
             sv.hpre, sv.fb, sv.z2, sv.ln2 = hpre, fb, z2, out.norm
             run.layers.append(sv)
@@ -843,7 +841,6 @@ class LayerSave:
     li: int = 0
     emd: bool = False
     qkv: torch.Tensor = None
-    vt: torch.Tensor = None
     pqk: torch.Tensor = None
     ctx: torch.Tensor = None
     lse: torch.Tensor = None

@@ -42,7 +42,7 @@ SIGNATURES = {
     "fbl_colsum_ws_floats": (_l, [_i]),
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
-    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
+    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
                                  _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
@@ -310,16 +310,14 @@ def head_transpose(v, vt, B, S, Sp, nh, head_major=False):
     _chk(load().fbl_head_transpose(_p(v), ldv, _p(vt), B, S, Sp, nh, sh, sb, sd, _stream()), "fbl_head_transpose")
 
 
-def disent_attn_fwd(q, k, vt, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0,
-                    vt_head_major=False, klen=None):
-    for t, n in ((q, "q"), (k, "k"), (pk, "pk"), (pq, "pq"), (ctx, "ctx"), (vt, "vt")):
+def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0, klen=None):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (pk, "pk"), (pq, "pq"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
-    assert relidx.numel() == 2 * S - 1 and mask.is_contiguous() and vt.is_contiguous()
-    ldq, ldk, ldp, ldo = _rows2d(q, "q"), _rows2d(k, "k"), _rows2d(pk, "pk"), _rows2d(ctx, "ctx")
+    assert relidx.numel() == 2 * S - 1 and mask.is_contiguous()
+    ldq, ldk, ldv, ldp, ldo = _rows2d(q, "q"), _rows2d(k, "k"), _rows2d(v, "v"), _rows2d(pk, "pk"), _rows2d(ctx, "ctx")
     assert _rows2d(pq, "pq") == ldp
-    sh, sb, sd = head_strides(B, Sp, nh, vt_head_major)
-    _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(vt), sh, sb, sd, _p(pk), _p(pq), ldp, _p(relidx),
+    _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
                                     _p(mask), _p(klen), float(scale), float(p_drop), int(seed), _p(ctx), ldo, _p(lse), B,
                                     S, Sp, nh, span2, _stream()), "fbl_disent_attn_fwd")
 

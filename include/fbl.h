@@ -152,13 +152,14 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
 /* Fused disentangled self-attention forward (one launch per layer execution):
  *   score[i,j] = scale*(Q_i.K_j + Q_i.PK[idx(i-j)] + K_j.PQ[idx(i-j)]),  masked softmax (masked -> 0, fully masked
  *   rows -> 0), attention-prob dropout, ctx = P.V.   head_dim = 64, S <= 512.
- *   q/k: bf16 rows b*S+s, head h at column h*64 (strides ldq/ldk); vt from fbl_head_transpose (strides v_*);
+ *   q/k/v: bf16 rows b*S+s, head h at column h*64 (row strides ldq/ldk/ldv) -- V is consumed row-major, its transposed
+ *   MFMA fragments come from ds_read_b64_tr_b16;
  *   pk/pq bf16 [2*span, ldp]; relidx int16 [2S-1]: relidx[d+S-1] = clamp(bucket(d)+span, 0, 2span-1);
  *   mask int32 [B,S]; klen int32 [B] (optional): last valid position + 1 -- tiles beyond it are exactly zero and are
  *   skipped; out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
-int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t v_sh,
-                        int64_t v_sb, int64_t v_sd, const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
+int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                        const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                         const int32_t* mask, const int32_t* klen, float scale, float p_drop, uint64_t seed, void* ctx,
                         int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2, void* stream);
 

@@ -469,11 +469,9 @@ def _klen(mask):
 def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None):
     H = nh * 64
     Sp = (S + 63) // 64 * 64
-    vt = torch.empty(B, nh, 64, Sp, dtype=BF16, device=DEV)
-    L.head_transpose(qkv[:, 2 * H:], vt, B, S, Sp, nh)
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.empty(B, nh, S, device=DEV)
-    L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx,
+    L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx,
                       lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen)
     return ctx, lse
 

@@ -26,10 +26,8 @@ eng.sk_ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
 P_ATT = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 run.B, run.S, run.mask_i32, run.p_att, run.klen = B, S, mask.view(-1), P_ATT, klen
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
-    vt = torch.empty(B, nh, 64, Sp, dtype=torch.bfloat16, device=dev)
-    L.head_transpose(qkv[:, 2 * H:], vt, B, S, Sp, nh)
     ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev); lse = torch.empty(B, nh, S, device=dev)
-    L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], vt, pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx, lse,
+    L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx, lse,
                       B, S, Sp, nh, span2, klen=klen, p_drop=P_ATT, seed=7)
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 7
     dctx = torch.randn(B * S, H, device=dev).to(torch.bfloat16)
