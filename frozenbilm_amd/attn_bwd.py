@@ -34,17 +34,14 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
 
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
     L.attn_rowdot(dctx, sv.ctx, Dv, B, S, nh)
-    dOT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
-    L.head_transpose(dctx, dOT, B, S, Sp, nh, head_major=True)
     L.head_transpose(k, KT, B, S, Sp, nh, head_major=True)
     L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
-    L.disent_attn_bwd_ds(q, k, v, dctx, dOT, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
-                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, t_head_major=True, klen=klen)
-    del dOT
+    L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
+                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)

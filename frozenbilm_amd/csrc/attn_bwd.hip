@@ -46,7 +46,6 @@ __global__ void rowdot_kernel(const bf16* dO, const bf16* O, long ld, float* out
 struct BwdAArgs {
   const bf16* q; const bf16* k; const bf16* v; long ldq;  // row-major [B*S, ld], head h at col h*64
   const bf16* dO; long ldo;                               // row-major [B*S, ldo]
-  const bf16* dOT; long t_sh, t_sb, t_sd;                 // transposed dO: index h*sh + b*sb + d*sd + s
   const bf16* pk; const bf16* pq; long ldp;
   const int16_t* relidx; const int32_t* mask; const int32_t* klen;
   const float* lse; const float* Dv;                      // [B,nh,S]
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
   const float k2 = a.scale * LOG2E;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
-  const bf16* dOTh = a.dOT + h * a.t_sh + b * a.t_sb;
   const int kl = a.klen ? min(a.klen[b], S) : S;
   const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;  // tiles beyond the last valid position: dS = 0 (never read), dV = 0
   __syncthreads();
@@ -172,11 +170,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
     store_tile(R);
     __syncthreads();
     if (it + 1 < nqt) load_qd(it + 1, R);
-    // dO^T tile of THIS query tile (A operand of dV^T += dO^T . P): global -> registers now, -> LDS (over the dead PK
-    // window) after the bias GEMMs; its latency hides under the score / bias MFMAs
-    bf16x8 dts[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) dts[t] = *(const bf16x8*)(dOTh + (long)(srow + t * 32) * a.t_sd + i0 + sch * 8);
     // sub-window offsets: this wave's 16 keys (T2) and each 16-query tile (T1)
     const int base2 = idx[i0 - (j0 + w * 16 + 15) + tq];  // absolute table row of T2w[.][0]
     const int off2 = base2 - r_lo;
@@ -219,8 +212,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       }
     }
     if (it + 1 < nqt) load_win(it + 1, R);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) *(bf16x8*)(smem + A_PK + (srow + t * 32) * (LDV * 2) + sch * 16) = dts[t];  // PK window is dead
     // ---- dP = dO.V^T, dS = P*(dP - D)*scale; packed to bf16 at once (dsb: dS, pfh: dropped-out P for the dV MFMA)
     bf16x4 dsb[4], pfh[4];
 #pragma unroll
@@ -246,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
         pfh[nt][r] = f2bf(pv * keep[r]);
       }
     }
-    __syncthreads();  // dO^T tile visible; every wave is done gathering from T1 / T2 (reused below as dS staging)
+    __syncthreads();  // every wave is done gathering from T1 / T2 (reused below as dS staging)
     // ---- (4) dV^T += dO^T . drop(P):  k-slot e of step kk <-> query kk*32 + (e>>2)*16 + g*4 + (e&3)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -258,15 +249,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const char* drow = smem + A_PK + (dt * 16 + c) * (LDV * 2) + (kk * 32 + g * 4) * 2;
-        const bf16x4 v0 = *(const bf16x4*)drow;
-        const bf16x4 v1 = *(const bf16x4*)(drow + 32);
-        bf16x8 af;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          af[e] = v0[e];
-          af[4 + e] = v1[e];
-        }
+        // dO^T fragment (row d = dt*16 + c, queries kk*32 + g*4 + {0..3} and +16) read transposed out of the swizzled
+        // row-major dO tile that already feeds the dP MFMAs: lane (g, c) hands in 4 contiguous d of query row r
+        const int r = kk * 32 + g * 4 + (c >> 2);
+        const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        union { tr16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = lds_tr16((const bf16*)(smem + A_DOS + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
+        u.h[1] = lds_tr16((const bf16*)(smem + A_DOS + (r + 16) * 128 + ((ch ^ ((r + 16) & 7)) << 4) + sub));
+        const bf16x8 af = u.v;
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, dv[dt], 0, 0, 0);
       }
     }
@@ -503,16 +493,15 @@ extern "C" int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float*
 }
 
 extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO,
-                                      int64_t ldo, const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd,
+                                      int64_t ldo,
                                       const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                                       const int32_t* mask, const int32_t* klen, const float* lse, const float* Dv, float scale, float p_drop,
                                       uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
                                       int nh, int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
-  if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4) || (t_sd % 8) || (t_sb % 8) || (t_sh % 8)) return FBL_ERR_ALIGN;
+  if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
-  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)dOT, t_sh, t_sb,
-             t_sd, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
+  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
              (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2};
   static bool attr_set = false;
   if (!attr_set) {

@@ -45,7 +45,7 @@ SIGNATURES = {
     "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
                                  _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
+    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
@@ -328,14 +328,13 @@ def attn_rowdot(dO, O, out, B, S, nh):
     _chk(load().fbl_attn_rowdot(_p(dO), _p(O), ld, _p(out), B, S, nh, _stream()), "fbl_attn_rowdot")
 
 
-def disent_attn_bwd_ds(q, k, v, dO, dOT, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
-                       p_drop=0.0, seed=0, t_head_major=True, klen=None):
+def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
+                       p_drop=0.0, seed=0, klen=None):
     ldq = _rows2d(q, "q")
     assert _rows2d(k, "k") == ldq and _rows2d(v, "v") == ldq
     ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
     assert _rows2d(pq, "pq") == ldp
-    sh, sb, sd = head_strides(B, Sp, nh, t_head_major)
-    _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(dOT), sh, sb, sd, _p(pk), _p(pq), ldp,
+    _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(pk), _p(pq), ldp,
                                        _p(relidx), _p(mask), _p(klen), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
                                        _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, _stream()),
          "fbl_disent_attn_bwd_ds")

@@ -177,12 +177,12 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  *                              workgroup writes one contiguous block: GT[h][b][t][r][32] with t = row/32, r in
  *                              [0, gt_rcnt) standing for table row gt_rmin + r (the range of relidx; others are 0).
  *                              lin_span: |i-j| < lin_span => relidx is injective there (identity buckets, = position_buckets/2;
- *                              0 if unknown): those entries are scattered with plain LDS stores instead of atomics.  * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
+ *                              0 if unknown): those entries are scattered with plain LDS stores instead of atomics.
+ * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
  * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
-                           const void* dOT, int64_t t_sh, int64_t t_sb, int64_t t_sd, const void* pk, const void* pq,
-                           int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen, const float* lse,
+                           const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen, const float* lse,
                            const float* Dv,
                            float scale, float p_drop, uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B,
                            int S, int Sp, int nh, int span2, void* stream);
