@@ -230,16 +230,16 @@ def measure_gemm_roofline(L, step_fn):
     top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:8]
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
     # HBM-side bytes of the same kernel family over the same step, from separate rocprofv3 --pmc passes (FETCH_SIZE x2
-    # for gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/r01_run11_traffic.json): PMC passes cannot run inside
+    # for gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/r01_run13_traffic.json): PMC passes cannot run inside
     # this process, so the committed summary is read back and divided by this run's GEMM call count.
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_run11_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_run13_traffic.json")
     if os.path.exists(tpath) and recs:
         with open(tpath) as f:
             tj = json.load(f)
         gb = sum(v["GB_per_step"] for k, v in tj.items() if k.startswith("gemm_bf16_nt_kernel"))
         traffic = gb * 1e9 / len(recs)
-        traffic_src = ("profiles/r01_run11_traffic.json: %.1f GB/step over the gemm_bf16_nt_kernel family (rocprofv3 --pmc "
+        traffic_src = ("profiles/r01_run13_traffic.json: %.1f GB/step over the gemm_bf16_nt_kernel family (rocprofv3 --pmc "
                        "FETCH_SIZE, WRITE_SIZE passes over this command), bytes per GEMM call" % gb)
     return {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
