@@ -22,24 +22,30 @@ namespace {
 using namespace attn;
 
 // ------------------------------------------------------------------------------------------- D_i = dO_i . O_i
+// 8 lanes per (row, head): lane c reads the c-th 16-byte chunk of both 128-byte head rows (a wave covers 8 consecutive
+// heads = 1 KiB contiguous per operand), then a 3-step shuffle reduction.
 __global__ void rowdot_kernel(const bf16* dO, const bf16* O, long ld, float* out, int B, int S, int nh) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, head)
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = gid >> 3;  // (row, head)
+  const int c = (int)(gid & 7);
   const long total = (long)B * S * nh;
-  if (idx >= total) return;
-  const long row = idx / nh;
-  const int h = (int)(idx % nh);
-  const bf16* a = dO + row * ld + h * 64;
-  const bf16* b = O + row * ld + h * 64;
+  const bool live = idx < total;
+  const long row = live ? idx / nh : 0;
+  const int h = live ? (int)(idx % nh) : 0;
   float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const bf16x8 x = *(const bf16x8*)(a + c * 8);
-    const bf16x8 y = *(const bf16x8*)(b + c * 8);
+  if (live) {
+    const bf16x8 x = *(const bf16x8*)(dO + row * ld + h * 64 + c * 8);
+    const bf16x8 y = *(const bf16x8*)(O + row * ld + h * 64 + c * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
   }
-  const int bb = (int)(row / S), ss = (int)(row % S);
-  out[((long)bb * nh + h) * S + ss] = s;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (live && c == 0) {
+    const int bb = (int)(row / S), ss = (int)(row % S);
+    out[((long)bb * nh + h) * S + ss] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------- kernel A
@@ -486,7 +492,7 @@ extern "C" int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float*
   if (ld % 8) return FBL_ERR_ALIGN;
   const long total = (long)B * S * nh;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)dO, (const bf16*)O, (long)ld, out, B, S, nh);
   FBL_CHECK_LAUNCH();
   return 0;
