@@ -306,3 +306,35 @@ def test_step_state_dies_with_the_loss_no_gc_needed():
         assert not [o for o in gc.get_objects() if isinstance(o, Run)]
     finally:
         gc.enable()
+
+
+def test_full_size_batch_independence_xlarge():
+    """BASELINE config 2 at its full size (DeBERTa-v2-XLarge dims, 24 layers, B=32, T=10x1024, L=256, ragged): a sample's
+    logits must not depend on what else is in the batch -- the B=32 forward equals the two B=16 halves row for row
+    (padding, key-tile skipping, tile quantisation and the round-filling GEMM splits all change with the batch)."""
+    import bench as Bn
+    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
+
+    cfg = DebertaV2Config()
+    torch.manual_seed(0)
+    m = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1).to(DEV).eval()
+    batch = Bn.synth_batch(32, 10, 1024, 256, cfg.vocab_size, seed=3, device=torch.device(DEV))
+    cols = torch.arange(0, cfg.vocab_size, 997, device=DEV)
+
+    def run(sl):
+        with torch.no_grad():
+            out = m(**{k: v[sl] for k, v in batch.items()})
+        lg = out.logits
+        return lg[:, :, cols].float().clone(), lg.argmax(-1), out.loss.item()
+
+    full, am_full, loss_full = run(slice(0, 32))
+    lo, am_lo, loss_lo = run(slice(0, 16))
+    hi, am_hi, loss_hi = run(slice(16, 32))
+    valid = torch.cat([batch["video_mask"], batch["attention_mask"]], 1).bool()
+    halves, am_halves = torch.cat([lo, hi], 0), torch.cat([am_lo, am_hi], 0)
+    err = (full - halves)[valid].abs().max().item()
+    assert err < 1e-3, err
+    assert torch.equal(am_full[valid], am_halves[valid])  # token indices bit-exact
+    n = (batch["labels"] != -100).sum(1).float()
+    want = (loss_lo * n[:16].sum() + loss_hi * n[16:].sum()) / n.sum()  # mean over labelled rows
+    assert abs(loss_full - want.item()) < 1e-4, (loss_full, want.item())
