@@ -338,3 +338,31 @@ def test_full_size_batch_independence_xlarge():
     n = (batch["labels"] != -100).sum(1).float()
     want = (loss_lo * n[:16].sum() + loss_hi * n[16:].sum()) / n.sum()  # mean over labelled rows
     assert abs(loss_full - want.item()) < 1e-4, (loss_full, want.item())
+
+
+def test_full_size_backward_linearity_xlarge():
+    """Full BASELINE size, backward: gradients are linear in the loss scale (2 x loss -> 2 x every gradient; power-of-two
+    scaling commutes with bf16 rounding, so only the fp32 atomic orders differ), finite, and non-zero for all 298
+    trainable tensors."""
+    import bench as Bn
+    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
+
+    cfg = DebertaV2Config()
+    torch.manual_seed(0)
+    m = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1).to(DEV).eval()
+    batch = Bn.synth_batch(32, 10, 1024, 256, cfg.vocab_size, seed=4, device=torch.device(DEV))
+    grads = []
+    for scale in (1.0, 2.0):
+        for p in m.parameters():
+            p.grad = None
+        loss = m(**batch).loss
+        (loss * scale).backward()
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.requires_grad})
+    assert len(grads[0]) == 298
+    worst = 0.0
+    for n, g1 in grads[0].items():
+        g2 = grads[1][n]
+        assert torch.isfinite(g1).all() and g1.abs().max().item() > 0, n
+        rel = (g2 - 2 * g1).norm().item() / (2 * g1.norm().item() + 1e-30)
+        worst = max(worst, rel)
+    assert worst < 2e-3, worst
