@@ -524,12 +524,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, long l
 }
 __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, long ldv, const int64_t* labels,
                                                           const int32_t* rows, int V, int Vp, const float* row_lse,
-                                                          const float* loss_sum_cnt, float gscale, bf16* out) {
+                                                          const float* loss_sum_cnt, float gscale, const float* gscale_dev,
+                                                          bf16* out) {
   const int r = blockIdx.x;
   const int row = rows[r];
   const int lab = (int)labels[row];
   const float lse = row_lse[row];
-  const float sc = gscale / fmaxf(loss_sum_cnt[1], 1.0f);
+  const float sc = gscale * (gscale_dev ? gscale_dev[0] : 1.0f) / fmaxf(loss_sum_cnt[1], 1.0f);
   const float* x = logits + (long)row * ldv;
   bf16* o = out + (long)r * Vp;
   const bool vec = ((ldv & 3) == 0) && ((Vp & 3) == 0) && (((uintptr_t)logits & 15) == 0) && (((uintptr_t)out & 7) == 0);
@@ -807,11 +808,11 @@ extern "C" int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* label
 }
 extern "C" int fbl_ce_bwd_rows(const float* logits, int64_t ldv, const int64_t* labels, const int32_t* rows, int R,
                                int V, int Vp, const float* row_lse, const float* loss_sum_cnt, float gscale,
-                               void* dlogits_bf16, void* stream) {
+                               const float* gscale_dev, void* dlogits_bf16, void* stream) {
   if (R <= 0) return 0;
   if (Vp < V) return FBL_ERR_ARG;
   hipLaunchKernelGGL(ce_bwd_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, (long)ldv, labels, rows, V,
-                     Vp, row_lse, loss_sum_cnt, gscale, (bf16*)dlogits_bf16);
+                     Vp, row_lse, loss_sum_cnt, gscale, gscale_dev, (bf16*)dlogits_bf16);
   FBL_CHECK_LAUNCH();
   return 0;
 }

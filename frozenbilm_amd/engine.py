@@ -731,11 +731,13 @@ class Engine:
             R = rows.numel()
             if R > 0:
                 dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
+                # the incoming loss gradient stays on the device (read by the kernel): no host sync at backward start
+                gs = gloss.detach().to(F32) if (isinstance(gloss, torch.Tensor) and gloss.is_cuda) else float(gloss)
                 if compact:  # logits of the labelled rows only (training path)
                     ar = torch.arange(R, dtype=torch.int32, device=dev)
-                    L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+                    L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, gs, dlog)
                 else:
-                    L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, float(gloss), dlog)
+                    L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, gs, dlog)
                 self._head_bwd(run, rows, dlog, dq)
                 del dlog
         # ---- gradient handed in on the logits themselves (downstream losses): every token row

@@ -50,7 +50,7 @@ SIGNATURES = {
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
-    "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
     "fbl_scatter_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp]),
     "fbl_sumsq": (_i, [_vp, _l, _vp, _vp]),
@@ -357,10 +357,16 @@ def ce_fwd(logits, labels, V, row_lse, loss_sum_cnt):
 
 
 def ce_bwd_rows(logits, labels, rows, V, Vp, row_lse, loss_sum_cnt, gscale, dlogits):
+    """gscale: python float, or a 1-element fp32 device tensor (read by the kernel: no host sync)"""
     ldv = _rows2d(logits, "logits")
     _req(rows, torch.int32, "rows")
+    gdev = None
+    if isinstance(gscale, torch.Tensor):
+        gdev = gscale.reshape(1)
+        _req(gdev, torch.float32, "gscale")
+        gscale = 1.0
     _chk(load().fbl_ce_bwd_rows(_p(logits), ldv, _p(labels), _p(rows), rows.numel(), V, Vp, _p(row_lse),
-                                _p(loss_sum_cnt), float(gscale), _p(dlogits), _stream()), "fbl_ce_bwd_rows")
+                                _p(loss_sum_cnt), float(gscale), _p(gdev), _p(dlogits), _stream()), "fbl_ce_bwd_rows")
 
 
 def gather_rows_bf16(x, rows, out):

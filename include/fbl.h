@@ -195,11 +195,12 @@ int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_
  * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */
 int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* labels, int N, int V, float* row_lse,
                float* loss_sum_cnt, void* stream);
-/* dlogits_bf16[r, :] = (softmax(logits[rows[r]]) - onehot) * gscale[0]/count, zero-padded to Vp columns;
- * rows int32 [R] = indices of labelled rows. */
+/* dlogits_bf16[r, :] = (softmax(logits[rows[r]]) - onehot) * gscale * (gscale_dev ? gscale_dev[0] : 1) / count,
+ * zero-padded to Vp columns; rows int32 [R] = indices of labelled rows.  gscale_dev (device scalar, may be NULL) lets the
+ * incoming loss gradient stay on the GPU: no host synchronisation at the start of the backward. */
 int fbl_ce_bwd_rows(const float* logits, int64_t ldv, const int64_t* labels, const int32_t* rows, int R, int V,
-                    int Vp, const float* row_lse, const float* loss_sum_cnt, float gscale, void* dlogits_bf16,
-                    void* stream);
+                    int Vp, const float* row_lse, const float* loss_sum_cnt, float gscale, const float* gscale_dev,
+                    void* dlogits_bf16, void* stream);
 
 /* gathers rows: out_bf16[r, :] = in_bf16[rows[r], :] ; scatter-add fp32: out[rows[r], :] += in[r, :] */
 int fbl_gather_rows_bf16(const void* in, int64_t ld, const int32_t* rows, int R, int cols, void* out, void* stream);
