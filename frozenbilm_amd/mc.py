@@ -6,30 +6,23 @@ parallelism the gradient exchange waits for the last candidate's backward (``Gra
 """
 from __future__ import annotations
 
-import contextlib
-import math
-import sys
 from functools import reduce
 
 import torch
 import torch.nn.functional as F
 
-from .optim import FusedAdam
+from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
 from .util import dist
-from .util.metrics import MetricLogger
-from .util.misc import adjust_learning_rate, get_mask
 from .videoqa import mask_row_logits
 
 
 def candidate_scores(model, tokenizer, batch_dict, device, args):
     """mc.py:44-72,140-165: text[aid] is the batch of candidate `aid`; returns scores [B, n_candidates]."""
-    video = batch_dict["video"].to(device)
-    video_mask = get_mask(batch_dict["video_len"], video.size(1)).to(device)
+    video, video_mask = video_inputs(batch_dict, device)
     text = batch_dict["text"]
     scores = []
     for aid in range(len(text)):  # one forward per answer candidate id
-        encoded = tokenizer(text[aid], add_special_tokens=True, max_length=args.max_tokens, padding="longest",
-                            truncation=True, return_tensors="pt")
+        encoded = tokenize(tokenizer, text[aid], args)
         output = model(video=video, video_mask=video_mask, input_ids=encoded["input_ids"].to(device),
                        attention_mask=encoded["attention_mask"].to(device))
         logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
@@ -52,44 +45,26 @@ def mc_loss(scores, gt, n_choices):
 
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, args, max_norm: float = 0):
     model.train()
-    metric_logger = MetricLogger(delimiter="  ")
-    header = "Epoch: [{}]".format(epoch)
-    num_training_steps = int(len(data_loader) * args.epochs)
+    run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
+    # several forwards feed one step: under data parallelism the gradient exchange waits for the last backward pass
     reducer = getattr(model.engine(), "reducer", None) if hasattr(model, "engine") else None
-    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+    for i_batch, batch_dict in run:
         scores = candidate_scores(model, tokenizer, batch_dict, device, args)
         loss = mc_loss(scores, batch_dict["answer_id"].to(device), data_loader.dataset.mc)
-        loss_dict_reduced = dist.reduce_dict({"cls_loss": loss})
-        loss_value = sum(loss_dict_reduced.values()).item()
-        if not math.isfinite(loss_value):
-            print("Loss is {}, stopping training".format(loss_value))
-            print(loss_dict_reduced)
-            sys.exit(1)
-        optimizer.zero_grad()
-        with (reducer.accumulate() if reducer is not None else contextlib.nullcontext()):
-            loss.backward()
-        if isinstance(optimizer, FusedAdam):
-            optimizer.step(clip_max_norm=max_norm)
-        else:
-            if max_norm > 0:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-            optimizer.step()
-        adjust_learning_rate(optimizer, curr_step=epoch * len(data_loader) + i_batch,
-                             num_training_steps=num_training_steps, args=args)
-        metric_logger.update(loss=loss_value, **loss_dict_reduced)
-        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
-    metric_logger.synchronize_between_processes()
-    print("Averaged stats:", metric_logger)
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+        reduced, value = logged_loss("cls_loss", loss)
+        optimizer_step(loss, optimizer, model, max_norm, reducer=reducer)
+        run.schedule(optimizer, i_batch)
+        run.log(loss=value, **reduced)
+        run.log(lr=optimizer.param_groups[0]["lr"])
+    return run.finish()
 
 
 @torch.no_grad()
 def evaluate(model, tokenizer, data_loader, device, dataset_name, args, split="test", type_map={0: "all"}):
     model.eval()
-    metric_logger = MetricLogger(delimiter="  ")
-    header = f"{split}:"
+    run = EpochRunner(data_loader, args, f"{split}:")
     res = {}
-    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
+    for _, batch_dict in run:
         scores = candidate_scores(model, tokenizer, batch_dict, device, args)
         preds = scores.round().long().squeeze(1) if scores.shape[1] == 1 else scores.max(1).indices
         qids, types = batch_dict["qid"], batch_dict["type"]
@@ -101,8 +76,7 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, split="t
                 if type_map is not None and len(type_map) > 1:
                     res[qid]["type"] = int(type_)
                 res[qid]["acc"] = agreeings[i].item()
-            dico_reduced = dist.reduce_dict({"acc": agreeings.sum() / len(qids)})
-            metric_logger.update(acc=dico_reduced["acc"].item())
+            run.log(acc=dist.reduce_dict({"acc": agreeings.sum() / len(qids)})["acc"].item())
         else:  # hidden test set: predictions only (mc.py:205-207)
             for qid, pred in zip(qids, preds):
                 res[str(qid)] = int(pred.item())

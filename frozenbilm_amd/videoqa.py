@@ -6,26 +6,13 @@ returned ``logits`` (they are a differentiable output of the single autograd nod
 """
 from __future__ import annotations
 
-import math
-import sys
 from functools import reduce
 
 import torch
 import torch.nn.functional as F
 
-from .optim import FusedAdam
+from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
 from .util import dist
-from .util.metrics import MetricLogger
-from .util.misc import adjust_learning_rate, get_mask
-
-
-def _encode(batch_dict, tokenizer, device, args, text=None):
-    video = batch_dict["video"].to(device)
-    video_len = batch_dict["video_len"]
-    video_mask = get_mask(video_len, video.size(1)).to(device)
-    encoded = tokenizer(batch_dict["text"] if text is None else text, add_special_tokens=True, max_length=args.max_tokens,
-                        padding="longest", truncation=True, return_tensors="pt")
-    return video, video_mask, encoded
 
 
 def mask_row_logits(output_logits, encoded_ids, tokenizer, args):
@@ -64,47 +51,31 @@ def topk_agreement(logits, answer_id, dataset_name, thresholds):
 
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dataset_name, args, max_norm: float = 0):
     model.train()
-    metric_logger = MetricLogger(delimiter="  ")
-    header = "Epoch: [{}]".format(epoch)
-    num_training_steps = int(len(data_loader) * args.epochs)
-    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
-        video, video_mask, encoded = _encode(batch_dict, tokenizer, device, args)
+    run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
+    for i_batch, batch_dict in run:
+        video, video_mask = video_inputs(batch_dict, device)
+        encoded = tokenize(tokenizer, batch_dict["text"], args)
         output = model(video=video, video_mask=video_mask, input_ids=encoded["input_ids"].to(device),
                        attention_mask=encoded["attention_mask"].to(device))
         logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
         loss = vqa_loss(logits, batch_dict["answer_id"].to(device), dataset_name)
-        loss_dict_reduced = dist.reduce_dict({"cls_loss": loss})
-        loss_value = sum(loss_dict_reduced.values()).item()
-        if not math.isfinite(loss_value):
-            print("Loss is {}, stopping training".format(loss_value))
-            print(loss_dict_reduced)
-            sys.exit(1)
-        optimizer.zero_grad()
-        loss.backward()
-        if isinstance(optimizer, FusedAdam):
-            optimizer.step(clip_max_norm=max_norm)
-        else:
-            if max_norm > 0:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-            optimizer.step()
-        adjust_learning_rate(optimizer, curr_step=epoch * len(data_loader) + i_batch,
-                             num_training_steps=num_training_steps, args=args)
-        metric_logger.update(loss=loss_value, **loss_dict_reduced)
-        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
-    metric_logger.synchronize_between_processes()
-    print("Averaged stats:", metric_logger)
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+        reduced, value = logged_loss("cls_loss", loss)
+        optimizer_step(loss, optimizer, model, max_norm)
+        run.schedule(optimizer, i_batch)
+        run.log(loss=value, **reduced)
+        run.log(lr=optimizer.param_groups[0]["lr"])
+    return run.finish()
 
 
 @torch.no_grad()
 def evaluate(model, tokenizer, data_loader, device, dataset_name, args, thresholds=[1, 10], split="test",
              type_map={0: "all"}):
     model.eval()
-    metric_logger = MetricLogger(delimiter="  ")
-    header = f"{split}:"
+    run = EpochRunner(data_loader, args, f"{split}:")
     res = {}
-    for i_batch, batch_dict in enumerate(metric_logger.log_every(data_loader, args.print_freq, header)):
-        video, video_mask, encoded = _encode(batch_dict, tokenizer, device, args)
+    for _, batch_dict in run:
+        video, video_mask = video_inputs(batch_dict, device)
+        encoded = tokenize(tokenizer, batch_dict["text"], args)
         input_ids = encoded["input_ids"].to(device)
         attention_mask = encoded["attention_mask"].to(device)
         if not args.suffix and not args.use_context:  # remove sep token if not using the suffix (videoqa.py:152-156)
@@ -121,8 +92,7 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, threshol
                         "type": int(type_), "sub": sub}
             for x in thresholds:
                 res[qid][f"acc{x}"] = agreeings[x][i].sum().detach().cpu().item()
-        dico_reduced = dist.reduce_dict({"acc": agreeings[1].sum() / len(qids)})
-        metric_logger.update(acc=dico_reduced["acc"].item())
+        run.log(acc=dist.reduce_dict({"acc": agreeings[1].sum() / len(qids)})["acc"].item())
 
     all_res = dist.all_gather(res)
     results = reduce(lambda a, b: a.update(b) or a, all_res, {})
