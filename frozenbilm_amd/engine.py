@@ -83,6 +83,9 @@ class Engine:
         # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
         # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
         self.side = torch.cuda.Stream(device=dev)  # (stream priorities were measured: no effect on the interference)
+        # the full-logits GEMM of the forward gets its own stream: on `side` it would sit in front of the first dW
+        # kernels of the backward and every data-parallel bucket would wait 3.7 ms for an output nobody reads
+        self.side_logits = torch.cuda.Stream(device=dev)
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
@@ -504,14 +507,13 @@ class Engine:
                 L.ce_fwd(lc, run.labels_c, Vout, run.row_lse, run.loss_acc)
                 run.logits_c = lc
             loss_t = run.loss_acc[0] / run.loss_acc[1]
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
+            self.side_logits.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side_logits):
                 logits = torch.empty(N, ldv, dtype=F32, device=dev)
                 L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
                 run.logits_event = torch.cuda.Event()
-                run.logits_event.record(self.side)
-            hl.bf16.record_stream(self.side)
-            run.side_used = True
+                run.logits_event.record(self.side_logits)
+            hl.bf16.record_stream(self.side_logits)
             run.logits = logits
             return logits, loss_t
         logits = torch.empty(N, ldv, dtype=F32, device=dev)
@@ -601,6 +603,9 @@ class Engine:
             for t in (dyb, z, dz, xin_b):
                 t.record_stream(self.side)  # keep the allocator from recycling them before the side stream is done
             run.side_used = True
+            if self.reducer is not None:  # what a data-parallel bucket has to wait for: the dW work queued so far
+                run.dw_event = torch.cuda.Event()
+                run.dw_event.record(self.side)
         else:
             dw_work(self.sk_ws, self._cs_ws)
         return dx
@@ -830,8 +835,9 @@ class _Ready:
         self.eng, self.run, self.reducer = eng, run, reducer
 
     def ready(self, key):
-        if getattr(self.run, "side_used", False):
-            torch.cuda.current_stream().wait_stream(self.eng.side)
+        ev = getattr(self.run, "dw_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         self.reducer.ready(key)
 
     def finish(self):
