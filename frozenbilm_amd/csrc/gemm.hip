@@ -583,7 +583,12 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
     const long c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
     use_224 = c224 * 100 < c256 * 97;
   }
-  g.tiles_m = use_224 ? (M + 223) / 224 : (M + BT - 1) / BT;
+  // 64x128 tiles for tall, narrow problems whose 128x128 grid covers less than the chip (the adapter bottleneck
+  // projections: 8512 x 192 -> 134 workgroups): twice the workgroups, so twice the CUs pull operands from L2
+  static const int no64 = getenv("FBL_GEMM_NO64") ? atoi(getenv("FBL_GEMM_NO64")) : 0;
+  const bool use_64 = !use_big && !accumulate && !no64 && batch == 1 && M >= 2048 && splitk_ws_floats >= 0 &&
+                      (long)((M + 127) / 128) * ((N + 127) / 128) < 200;
+  g.tiles_m = use_224 ? (M + 223) / 224 : use_64 ? (M + 63) / 64 : (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
 #define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_, MI_)                                                           \
@@ -602,6 +607,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   do {                                                                \
     if (use_224) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 7);         \
     else if (use_big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 8);    \
+    else if (use_64) FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, false, 2);     \
     else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_, 4);                   \
   } while (0)
 #define FBL_GEMM_LAUNCH_SCHED(SCHED_)                                                                          \
