@@ -1,6 +1,6 @@
 """Benchmark of the FrozenBiLM masked-LM fwd+bwd hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one optimizer step of `main.train_one_epoch`'s body on a synthetic WebVid-shape batch already resident in
@@ -9,12 +9,20 @@ HBM: forward (train mode, dropout live as in the reference) + backward + [RCCL a
 T=10x1024 CLIP features, L=256 text tokens (S=266), seeded random weights (no checkpoints offline), bf16 MFMA compute.
 Weak scaling: per-GPU batch fixed, value = total samples/s over all ranks.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (gemm_bf16_nt_kernel, MFMA bound): algorithmic FLOPs of its launches in one
-                  step / their summed HIP-event durations (measured live on the launch stream in an instrumented
-                  replay of the same step), against the 2.5 PFLOP/s dense bf16 peak.
+Head: like `main.train_one_epoch` (main.py:67) the timed step reads only `.loss`; the model computes the prediction head
+on the labelled rows and fills the full [B,S,128100] logits on first access (SURVEY.md section 7 "full logits only when
+asked").  `--full-logits` reads `.logits` in every step (the reference's eager behaviour); the default run also times
+a few such steps and reports them as `with_full_logits`.  FLOP figures always use the reference-faithful op list.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline     -- the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs of its launches in one step / their
+                  summed HIP-event durations (measured live on the launch stream in an instrumented replay of the same
+                  step), against the 2.5 PFLOP/s dense bf16 peak; `executed_tflops_per_step` discloses what ran.
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this box's host cores on a
-                  bounded sample (B=1 sequence of the same shape, fwd+bwd), rank 0, N=1 only.
+                  bounded sample (B=2 sequences of the same shape, 1 warm-up + timed passes,
+                  fwd+bwd, threads = physical cores), rank 0, N=1 only.
+  eval_forward -- the eval-mode forward alone (north_star's ">= 40 % of peak on the fused forward"), timed in the same run.
+  host         -- host cost of enqueueing one step, measured where the GPU cannot hide it (same launch sequence at B=1).
 """
 from __future__ import annotations
 
@@ -73,12 +81,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eval-forward", action="store_true", help="time the eval forward only (reported under its own metric)")
+    ap.add_argument("--full-logits", action="store_true", help="read .logits in every timed step (reference-eager head)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the with_full_logits / eval_forward / host side measurements")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -106,12 +118,15 @@ def main():
     batch = synth_batch(B, T, F, Lt, cfg.vocab_size, seed=1 + rank, device=dev)
     t_build = time.time() - t_build
 
-    def step():
+    def step(full_logits=args.full_logits):
         if args.eval_forward:
             with torch.no_grad():
                 return model(**batch).loss
         opt.zero_grad(set_to_none=False)
-        loss = model(**batch).loss
+        out = model(**batch)
+        loss = out.loss
+        if full_logits:
+            out.logits  # materialises the [B,S,V] tensor (filled on first access)
         loss.backward()
         opt.step(clip_max_norm=0.1)
         return loss
@@ -137,7 +152,7 @@ def main():
         loss = step()
         marks[i + 1].record()
         host_marks.append(time.time())
-    t_host = time.time() - t0  # host time to ENQUEUE the steps (the loop only blocks on the per-step label-count sync)
+    t_host = time.time() - t0  # host time of the loop (it blocks once per step, on the label-row count at the start of forward)
     sync()
     dt = time.time() - t0
     if world > 1:
@@ -163,6 +178,48 @@ def main():
         roofline["whole_step_frac_of_peak"] = whole_step_tflops / PEAK_BF16_TFLOPS
         sync()
 
+    extras = {}
+    if not args.no_extras and not args.eval_forward:
+        def timed(fn, n):
+            for _ in range(2):
+                fn()
+            sync()
+            t = time.time()
+            for _ in range(n):
+                fn()
+            sync()
+            d = time.time() - t
+            if world > 1:
+                tm = torch.tensor([d], device=dev, dtype=torch.float64)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = tm.item()
+            return d / n
+
+        n_x = max(3, min(args.steps, 6))
+        if not args.full_logits:
+            d = timed(lambda: step(True), n_x)
+            extras["with_full_logits"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                          "note": "same step, .logits read every step: the [B,S,128100] fp32 tensor is produced"}
+        model.eval()
+
+        def fwd_only():
+            with torch.no_grad():
+                return model(**batch).loss
+
+        d = timed(fwd_only, n_x)
+        model.train()
+        extras["eval_forward"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                  "algorithmic_tflops": fwd_f * B / d / 1e12, "frac_of_peak": fwd_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
+                                  "note": "eval-mode forward with labels (loss on the labelled rows; logits filled on access)"}
+        # host cost of one step where the GPU cannot hide it: the same launch sequence on a B=1 batch
+        small = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=77, device=dev)
+        keep = dict(batch)
+        batch.clear(); batch.update(small)
+        d = timed(lambda: step(False), n_x)
+        batch.clear(); batch.update(keep)
+        extras["host"] = {"enqueue_ms_per_step": d * 1e3, "note": "wall time per step of the same launch sequence at B=1 "
+                          "(GPU work per launch negligible): upper bound of the host cost of a step"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only=args.eval_forward)
@@ -178,17 +235,41 @@ def main():
             "config": {"workload": f"DeBERTa-v2-XLarge({args.layers}L)+adapters ds8/8, B={B}/GPU, T=10x1024, L={Lt} (S={S}), "
                                    "MLM fwd+bwd+allreduce+clip+Adam, dropout 0.1 live, seeded random weights",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
-                       "head": "full fp32 logits [B,S,128100] in forward; CE + head backward on labelled rows",
+                       "head": ("full fp32 logits [B,S,128100] read every step; " if args.full_logits else
+                                "loss-only step as in main.py:67: full fp32 logits [B,S,128100] filled on access (not read here); ")
+                               + "CE + head backward on labelled rows",
                        "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted"},
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
-            "loss": loss_value, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
             "algorithmic_tflops_per_step": step_flops / 1e12,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build,
         }
+        out.update(extras)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+    environment torch.distributed.run would set, rendezvous on 127.0.0.1) and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def measure_gemm_roofline(L, step_fn):
@@ -229,45 +310,70 @@ def measure_gemm_roofline(L, step_fn):
         d[2] += f
     top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:8]
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    # HBM-side bytes of the same kernel family over the same step, from separate rocprofv3 --pmc passes (FETCH_SIZE x2
-    # for gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/r01_run13_traffic.json): PMC passes cannot run inside
-    # this process, so the committed summary is read back and divided by this run's GEMM call count.
+    # HBM-side bytes of the same kernel family over the same step come from separate rocprofv3 --pmc passes (FETCH_SIZE
+    # x2 for gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/*_traffic.json): PMC passes cannot run inside this
+    # process, so the newest COMMITTED summary is read back and divided by this run's GEMM call count ("source" says so).
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_run13_traffic.json")
-    if os.path.exists(tpath) and recs:
-        with open(tpath) as f:
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
+    if cands and recs:
+        with open(os.path.join(pdir, cands[-1])) as f:
             tj = json.load(f)
-        gb = sum(v["GB_per_step"] for k, v in tj.items() if k.startswith("gemm_bf16_nt_kernel"))
+        gb = sum(v["GB_per_step"] for k, v in tj.items() if k.startswith("gemm"))
         traffic = gb * 1e9 / len(recs)
-        traffic_src = ("profiles/r01_run13_traffic.json: %.1f GB/step over the gemm_bf16_nt_kernel family (rocprofv3 --pmc "
-                       "FETCH_SIZE, WRITE_SIZE passes over this command), bytes per GEMM call" % gb)
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "launches_per_step": len(recs),
+        traffic_src = ("committed: profiles/%s -- %.1f GB/step over the GEMM kernel family (rocprofv3 --pmc FETCH_SIZE, "
+                       "WRITE_SIZE passes over this command at the commit that wrote the file), bytes per GEMM call; not "
+                       "re-measured by this run" % (cands[-1], gb))
+    return {"bound": "mfma", "kernel": "gemm8_kernel / gemm_bf16_nt_kernel (bf16 MFMA GEMM family)", "achieved": ach,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "traffic_source": traffic_src, "launches_per_step": len(recs),
             "avg_launch_us": tot_ms * 1e3 / max(len(recs), 1), "gemm_ms_per_step": tot_ms,
+            "executed_gemm_tflops_per_step": tot_fl / 1e12,
             "top_shapes_MNKb_count_ms_tflops": [[list(k), v[0], round(v[1], 3), round(v[2] / (v[1] * 1e-3) / 1e12, 1)]
                                                 for k, v in top]}
 
 
 def measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only):
-    """CPU oracle (fp32 torch port of the reference path) on host cores, one sample of the benchmark shape."""
+    """CPU oracle (fp32 torch port of the reference path) on the host cores, SURVEY.md section 8d protocol: B=2 sequences
+    of the benchmark shape, one warm-up pass, then timed passes (2, or 1 when a pass takes longer than 20 s so that the
+    default run stays within minutes), torch threads = physical cores."""
     from oracle import deberta_oracle as O
 
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(int(phys))
     ocfg = O.OracleConfig(num_hidden_layers=cfg.num_hidden_layers)
     P = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if "position_ids" not in k}
     for k, v in P.items():
         v.requires_grad_(O.is_trainable(k) and not fwd_only)
-    cb = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=99, device="cpu")
-    cores = torch.get_num_threads()
-    t0 = time.time()
-    with torch.set_grad_enabled(not fwd_only):
-        out = O.forward(P, ocfg, **cb)
-        if not fwd_only:
-            out["loss"].backward()
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 sequence (T=10, L={Lt}, S={T + Lt}) {'forward' if fwd_only else 'fwd+bwd'} through the fp32 CPU oracle, "
-                      f"eval-mode math (no dropout), {dt:.1f} s wall, torch threads={cores}"}
+    Bc = 2
+    cb = synth_batch(Bc, T, F, Lt, cfg.vocab_size, seed=99, device="cpu")
+
+    def one_pass():
+        for v in P.values():
+            v.grad = None
+        t = time.time()
+        with torch.set_grad_enabled(not fwd_only):
+            out = O.forward(P, ocfg, **cb)
+            if not fwd_only:
+                out["loss"].backward()
+        return time.time() - t
+
+    warm = one_pass()
+    n_timed = 2 if warm < 20.0 else 1
+    times = [one_pass() for _ in range(n_timed)]
+    dt = sum(times) / len(times)
+    torch.set_num_threads(prev_threads)
+    return {"value": Bc / dt, "unit": "samples/s", "cores": int(phys), "kind": "port", "loadavg": os.getloadavg()[0],
+            "logical_cpus": os.cpu_count(),
+            "sample": f"B={Bc} sequences (T=10, L={Lt}, S={T + Lt}) {'forward' if fwd_only else 'fwd+bwd'} through the fp32 CPU "
+                      f"oracle, eval-mode math (no dropout): 1 warm-up pass ({warm:.1f} s) + {n_timed} timed "
+                      f"({', '.join('%.1f' % x for x in times)} s), torch threads={int(phys)} (physical cores)"}
 
 
 if __name__ == "__main__":

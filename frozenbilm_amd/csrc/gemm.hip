@@ -12,52 +12,22 @@
 // -> 16-byte fp32 / 8-byte bf16 epilogue stores.
 #include <stdlib.h>
 
-#include "fbl_common.h"
-#include "../../include/fbl.h"
+#include "gemm_common.h"
+
+using namespace fblgemm;
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int NXCD = 8;
 // Tile configurations (NW waves, wave grid WR x WC, each wave (MI*16) x 64 outputs; BM = BN = 32*NW):
 //   small: 128x128, 4 waves (2x2), MI=4  -> 69.6 KiB LDS, 2 workgroups/CU   (narrow / short GEMMs)
 //   big:   256x256, 8 waves (2x4), MI=8  -> 136 KiB LDS, 1 workgroup/CU     (1/3 fewer LDS bytes per MFMA)
+// (the large square-ish problems run the 8-phase kernel of gemm8.hip instead of the NW = 8 configuration)
 template <int NW> struct TileCfg {
   static constexpr int BM = 32 * NW, BN = 32 * NW;
   static constexpr int TILE_BYTES = BM * BK * 2;
   static constexpr int STAGE_BYTES = 2 * TILE_BYTES;
   static constexpr int SMEM_BYTES = (NW * 64 * 68 * 4 > 2 * STAGE_BYTES) ? NW * 64 * 68 * 4 : 2 * STAGE_BYTES;
 };
-
-struct GemmArgs {
-  const bf16* A;
-  const bf16* B;
-  long lda, ldb;
-  int M, N, K;
-  const float* bias;      // [N] or null
-  const float* rowscale;  // [M] or null: multiplies (alpha*acc + bias) per row before the activation
-  float alpha;
-  int act, aux_kind;
-  const void* aux;
-  long ld_aux;
-  float* out_f32;
-  bf16* out_bf16;
-  bf16* out_pre;  // pre-activation copy (bf16) or null
-  long ldc;
-  long sA, sB, sC, sAux, sBias;  // batch strides in elements
-  int splitk;
-  int tiles_m, tiles_n;
-  float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
-  int Nw;
-  const int32_t* kskip_len;  // optional: K is made of samples of kskip_steps k-steps; step j of sample b is all zero when 64*j >= kskip_len[b]
-  int kskip_steps;
-  long a_kblk;  // 0: A rows are K-contiguous.  >0: A is stored in 32-wide k blocks: A[m][k] at m*lda + (k/32)*a_kblk + k%32
-};
-
-__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // MI_: 16-row MFMA tiles per wave along M.  The tile is (32*MI_) x (32*NW); MI_ = NW gives the square 128/256 tiles,
 // MI_ = 7 with NW = 8 a 224x256 tile for shapes whose 256x256 grid leaves CUs idle (8512 rows = 38 x 224 exactly:
@@ -78,21 +48,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WC, wn = wave % WC;
 
-  // ---- tile mapping: XCD-aware (block b runs on XCD b%8) + grouped along M so neighbours share the B panel in L2
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int pid = blockIdx.x;
-  {
-    const int q = ntiles / NXCD, r = ntiles % NXCD;
-    const int xcd = pid % NXCD, idx = pid / NXCD;
-    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective remap
-  }
-  constexpr int GROUP_M = 8;
-  const int width = GROUP_M * g.tiles_n;
-  const int group = pid / width;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(g.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (pid % width) % gsz;
-  const int tn = (pid % width) / gsz;
+  int tm, tn;
+  tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int batch = blockIdx.y / g.splitk;
@@ -240,120 +197,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
   }
   }
 
-  // ---- epilogue.  Accumulators (lane: C[m = ..+mi*16+(lane&15)][4 consecutive n]) go through a wave-private LDS tile
-  // [64 m][64 n] so that global traffic is row-contiguous: one wave instruction covers 4 rows x 256 B (fp32) /
-  // 128 B (bf16) of C and of the aux operand, instead of 16 rows x 64/32 B.
-  constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
-  float* stage = (float*)smem + wave * (64 * LDW);
-  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
-  const long cbase = (long)batch * g.sC;
-  const long xbase = (long)batch * g.sAux;
-  const bool vec_ok = ((g.ldc & 3) == 0);
-  const int er = lane >> 4, ec = (lane & 15) * 4;  // this lane's row-within-quad and column offset
-  const int n4 = n0 + wn * 64 + ec;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias && (!SPLITK || (ks == 0 && !g.ws))) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
-  }
-  const bool full = (n4 + 3 < g.N);
-#pragma unroll
-  for (int half = 0; half < (MI + 3) / 4; ++half) {  // the wave tile leaves in slabs of (up to) 64 rows
-    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
-    // The aux operand of the slab is requested BEFORE the accumulators make their LDS round trip: issued inside the
-    // row loop, every iteration exposed a full global-load latency (32 dependent loads per wave on a 256x256 tile).
-    constexpr bool AUX_F32 = (AUX == FBL_AUX_ADD_F32);
-    const bool aux_fast = (AUX != FBL_AUX_NONE) && !SPLITK && full && ((g.ld_aux & 3) == 0);
-    f32x4 xa32[AUX_F32 ? 16 : 1];
-    bf16x4 xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? 16 : 1];
-    if (AUX != FBL_AUX_NONE && aux_fast) {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int m = min(m0 + wm * WROWS + half * 64 + it * 4 + er, g.M - 1);
-        const long ao = xbase + (long)m * g.ld_aux + n4;
-        if (it < cnt * 4) {
-          if (AUX_F32) xa32[it] = *(const f32x4*)((const float*)g.aux + ao);
-          else xa16[it] = *(const bf16x4*)((const bf16*)g.aux + ao);
-        }
-      }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-      if (half * 4 + mi < MI) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
-      }
-    if (n4 < g.N) {
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      if (it >= cnt * 4) break;
-      const int row = it * 4 + er;
-      const int m = m0 + wm * WROWS + half * 64 + row;
-      if (m >= g.M) continue;
-      const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
-      const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
-      float v[4], pre[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (a4[r] * g.alpha + bv[r]) * rs;
-      if (SPLITK) {
-        if (g.ws) {  // plain 16-byte stores of the partial tile; folded into out_f32 by splitk_reduce_kernel
-          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-          for (int r = 0; r < 4; ++r)
-            if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r]);
-        }
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pre[r] = v[r];
-        if (ACT == FBL_ACT_GELU) v[r] = gelu_erf(v[r]);
-        else if (ACT == FBL_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-        else if (ACT == FBL_ACT_GELU_GRAD) gelu_and_grad(pre[r], &v[r], &pre[r]);
-      }
-      if (AUX != FBL_AUX_NONE) {
-        const long ao = xbase + (long)m * g.ld_aux + n4;
-        float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (AUX == FBL_AUX_ADD_F32) {
-          if (aux_fast) {
-            const f32x4 t = xa32[AUX_F32 ? it : 0];
-            x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
-          } else {
-            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = ((const float*)g.aux)[ao + r];
-          }
-        } else {
-          if (aux_fast) {
-            const bf16x4 t = xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? it : 0];
-            x[0] = bf2f(t[0]); x[1] = bf2f(t[1]); x[2] = bf2f(t[2]); x[3] = bf2f(t[3]);
-          } else {
-            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = bf2f(((const bf16*)g.aux)[ao + r]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (AUX == FBL_AUX_ADD_F32 || AUX == FBL_AUX_ADD_BF16) v[r] += x[r];
-          else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(x[r]);
-          else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (x[r] > 0.f) ? v[r] : 0.f;
-          else if (AUX == FBL_AUX_MUL_BF16) v[r] *= x[r];
-        }
-      }
-      const long co = cbase + (long)m * g.ldc + n4;
-      if (full && vec_ok) {
-        if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
-        if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        if (g.out_pre) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};
-      } else {
-        for (int r = 0; r < 4; ++r) {
-          if (n4 + r >= g.N) break;
-          if (g.out_f32) g.out_f32[co + r] = v[r];
-          if (g.out_bf16) g.out_bf16[co + r] = f2bf(v[r]);
-          if (g.out_pre) g.out_pre[co + r] = f2bf(pre[r]);
-        }
-      }
-    }
-    }
-  }
+  // ---- epilogue (gemm_common.h): slabs of 64 rows of this wave's tile through a wave-private LDS staging tile
+  gemm_epilogue<ACT, AUX, SPLITK, MI>(g, smem, wave, lane, acc, m0 + wm * WROWS, 64, n0 + wn * 64 + (lane & 15) * 4, batch, ks);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -490,13 +335,14 @@ __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, 
 
 }  // namespace
 
-extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
-                                const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
-                                const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
-                                int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
-                                int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
-                                int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
-                                void* stream) {
+// p_drop > 0 (ReLU epilogue only): dropout of the activated output, element (m, n) keyed by (drop_seed, m*ldc + n)
+static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                        const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
+                        const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
+                        int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                        int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
+                        int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
+                        float p_drop, uint64_t drop_seed, void* stream) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
@@ -526,10 +372,16 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.a_kblk = a_kblock_stride;
   g.kskip_len = kskip_len;
   g.kskip_steps = kskip_steps;
+  g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
+  if (p_drop > 0.f) {
+    if (act != FBL_ACT_RELU || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
+    g.drop_thresh = fbl_drop_thresh(p_drop);
+    g.drop_inv_keep = 1.f / (1.f - p_drop);
+  }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
-  const bool big = !force_small && !accumulate && batch == 1 && M >= 2048 && N >= 1024 &&
+  const bool big = !force_small && !accumulate && batch == 1 && p_drop <= 0.f && M >= 2048 && N >= 1024 &&
                    ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
   if (big && splitk_ws_floats >= 0) {  // (negative values mark the two halves of an already split launch)
     // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
@@ -549,17 +401,18 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
       const int tm_big = (int)((total - rem) / tn);             // whole rounds worth of M tiles
       const int m_big = tm_big * 256;
       if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
-        int rc = fbl_gemm_bf16_nt(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
-                                  out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0, stream);
+        int rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
+                              out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
+                              p_drop, drop_seed, stream);
         if (rc) return rc;
         const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
-        return fbl_gemm_bf16_nt((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
+        return gemm_nt_impl((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
                                 rowscale ? rowscale + m_big : nullptr, alpha, act, aux_kind,
                                 aux ? (const char*)aux + (size_t)m_big * ld_aux * aux_es : nullptr, ld_aux,
                                 out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
                                 out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
                                 out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
-                                1, nullptr, -2, a_kblock_stride, nullptr, 0, stream);
+                                1, nullptr, -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, stream);
       }
     }
   }
@@ -591,6 +444,17 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   g.tiles_m = use_224 ? (M + 223) / 224 : use_64 ? (M + 63) / 64 : (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
+  // The 8-phase kernel (gemm8.hip) takes every launch of the 256-row configurations it is instantiated for, including
+  // the shapes the 2-stage kernel ran with 224x256 tiles (measured: [8512,1536,6144] 915 -> 1139 TFLOP/s although only
+  // 204 of 256 CUs get a tile).  FBL_GEMM8=0 switches it off, FBL_GEMM8=1 keeps the 224x256 shapes on the old kernel.
+  static const int gemm8_mode = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 2;
+  if (use_big && gemm8_mode > 0 && (!use_224 || gemm8_mode >= 2) && gemm8_eligible(g)) {
+    GemmArgs g8 = g;
+    g8.tiles_m = (M + 255) / 256;
+    g8.tiles_n = (N + 255) / 256;
+    const int rc8 = launch_gemm8(g8, act, aux_kind, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
+    if (rc8 != FBL_ERR_ARG) return rc8;
+  }
 #define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_, MI_)                                                           \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \
@@ -662,6 +526,27 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
   }
   FBL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                                const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
+                                const void* aux, int64_t ld_aux, float* out_f32, void* out_bf16, void* out_pre_bf16,
+                                int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                                int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
+                                int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
+                                void* stream) {
+  return gemm_nt_impl(A, lda, B, ldb, M, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32, out_bf16,
+                      out_pre_bf16, ldc, batch, strideA, strideB, strideC, strideAux, strideBias, splitk, splitk_ws,
+                      splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream);
+}
+
+// z[M, A] = dropout(relu(x[M,K] . Wd[A,K]^T + bd)): the adapter's down-projection with ReLU AND dropout in the GEMM
+// epilogue (one launch instead of GEMM + fbl_dropout_bf16).  Element (m, a) is keyed by (seed, m*ldz + a).
+extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, int64_t ldw, int M, int A, int K,
+                                    const float* bias, float p_drop, uint64_t seed, void* z_bf16, int64_t ldz,
+                                    void* stream) {
+  return gemm_nt_impl(x_bf16, ldx, wd_bf16, ldw, M, A, K, bias, nullptr, 1.0f, FBL_ACT_RELU, FBL_AUX_NONE, nullptr, 0,
+                      nullptr, z_bf16, nullptr, ldz, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream);
 }
 
 extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

@@ -1,0 +1,199 @@
+// Pieces shared by the bf16 MFMA GEMM kernels of libfbl (gemm.hip: 2-stage tiles; gemm8.hip: 8-phase 256x256 tile):
+// the argument block, the LDS-DMA helper, the XCD-aware tile mapping and the fused epilogue.
+#pragma once
+#include "fbl_common.h"
+#include "../../include/fbl.h"
+
+namespace fblgemm {
+
+constexpr int BK = 64;
+constexpr int NXCD = 8;
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  long lda, ldb;
+  int M, N, K;
+  const float* bias;      // [N] or null
+  const float* rowscale;  // [M] or null: multiplies (alpha*acc + bias) per row before the activation
+  float alpha;
+  int act, aux_kind;
+  const void* aux;
+  long ld_aux;
+  float* out_f32;
+  bf16* out_bf16;
+  bf16* out_pre;  // pre-activation copy (bf16) or null
+  long ldc;
+  long sA, sB, sC, sAux, sBias;  // batch strides in elements
+  int splitk;
+  int tiles_m, tiles_n;
+  float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
+  int Nw;
+  const int32_t* kskip_len;  // optional: K is made of samples of kskip_steps k-steps; step j of sample b is all zero when 64*j >= kskip_len[b]
+  int kskip_steps;
+  long a_kblk;  // 0: A rows are K-contiguous.  >0: A is stored in 32-wide k blocks: A[m][k] at m*lda + (k/32)*a_kblk + k%32
+  // post-activation dropout of the epilogue (adapter bottleneck, model/adapter.py:39-41): element (m, n) is keyed by
+  // (drop_seed, m*drop_ld + n) exactly like fbl_dropout_bf16 on the [M, drop_ld] output; drop_thresh == 0 -> off
+  uint64_t drop_seed;
+  uint32_t drop_thresh;
+  float drop_inv_keep;
+  long drop_ld;
+};
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Tile mapping: XCD-aware (block b runs on XCD b%8; bijective remap so each XCD owns a contiguous run of tiles) +
+// grouped along M so neighbours share the B panel in their XCD's L2.
+__device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n, int* tm, int* tn) {
+  const int ntiles = tiles_m * tiles_n;
+  {
+    const int q = ntiles / NXCD, r = ntiles % NXCD;
+    const int xcd = pid % NXCD, idx = pid / NXCD;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = pid / width;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  *tm = first_m + (pid % width) % gsz;
+  *tn = (pid % width) / gsz;
+}
+
+// ---- epilogue.  Accumulators (lane: C[m = ..+mi*16+(lane&15)][4 consecutive n]) go through a wave-private LDS tile
+// [64 m][64 n] so that global traffic is row-contiguous: one wave instruction covers 4 rows x 256 B (fp32) /
+// 128 B (bf16) of C and of the aux operand, instead of 16 rows x 64/32 B.
+//   acc[ni][mi]: 16x16 tile ni (of 4) along n, mi (of MI) along m.  The wave's rows leave in slabs of 64: slab `half`
+//   starts at global row m_first + half*m_slab_stride; this lane's 4 staged columns (lane&15)*4.. map to the global
+//   columns n4..n4+3.
+template <int ACT, int AUX, bool SPLITK, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
+                                              int m_first, int m_slab_stride, int n4, int batch, int ks) {
+  constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
+  float* stage = (float*)smem + wave * (64 * LDW);
+  const int frow = lane & 15, fg = lane >> 4;
+  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+  const long cbase = (long)batch * g.sC;
+  const long xbase = (long)batch * g.sAux;
+  const bool vec_ok = ((g.ldc & 3) == 0);
+  const int er = lane >> 4, ec = (lane & 15) * 4;  // this lane's row-within-quad and staged column offset
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && (!SPLITK || (ks == 0 && !g.ws))) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
+  }
+  const bool full = (n4 + 3 < g.N);
+#pragma unroll
+  for (int half = 0; half < (MI + 3) / 4; ++half) {  // the wave tile leaves in slabs of (up to) 64 rows
+    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
+    const int mslab = m_first + half * m_slab_stride;
+    // The aux operand of the slab is requested BEFORE the accumulators make their LDS round trip: issued inside the
+    // row loop, every iteration exposed a full global-load latency (32 dependent loads per wave on a 256x256 tile).
+    constexpr bool AUX_F32 = (AUX == FBL_AUX_ADD_F32);
+    const bool aux_fast = (AUX != FBL_AUX_NONE) && !SPLITK && full && ((g.ld_aux & 3) == 0);
+    f32x4 xa32[AUX_F32 ? 16 : 1];
+    bf16x4 xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? 16 : 1];
+    if (AUX != FBL_AUX_NONE && aux_fast) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = min(mslab + it * 4 + er, g.M - 1);
+        const long ao = xbase + (long)m * g.ld_aux + n4;
+        if (it < cnt * 4) {
+          if (AUX_F32) xa32[it] = *(const f32x4*)((const float*)g.aux + ao);
+          else xa16[it] = *(const bf16x4*)((const bf16*)g.aux + ao);
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      if (half * 4 + mi < MI) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+      }
+    if (n4 < g.N) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (it >= cnt * 4) break;
+      const int row = it * 4 + er;
+      const int m = mslab + row;
+      if (m >= g.M) continue;
+      const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
+      const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
+      float v[4], pre[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (a4[r] * g.alpha + bv[r]) * rs;
+      if (SPLITK) {
+        if (g.ws) {  // plain 16-byte stores of the partial tile; folded into out_f32 by splitk_reduce_kernel
+          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r]);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pre[r] = v[r];
+        if (ACT == FBL_ACT_GELU) v[r] = gelu_erf(v[r]);
+        else if (ACT == FBL_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        else if (ACT == FBL_ACT_GELU_GRAD) gelu_and_grad(pre[r], &v[r], &pre[r]);
+      }
+      if (ACT == FBL_ACT_RELU && g.drop_thresh) {  // dropout(relu(.)) of the adapter bottleneck, same keys as fbl_dropout_bf16
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)m * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
+      }
+      if (AUX != FBL_AUX_NONE) {
+        const long ao = xbase + (long)m * g.ld_aux + n4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (AUX == FBL_AUX_ADD_F32) {
+          if (aux_fast) {
+            const f32x4 t = xa32[AUX_F32 ? it : 0];
+            x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
+          } else {
+            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = ((const float*)g.aux)[ao + r];
+          }
+        } else {
+          if (aux_fast) {
+            const bf16x4 t = xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? it : 0];
+            x[0] = bf2f(t[0]); x[1] = bf2f(t[1]); x[2] = bf2f(t[2]); x[3] = bf2f(t[3]);
+          } else {
+            for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = bf2f(((const bf16*)g.aux)[ao + r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (AUX == FBL_AUX_ADD_F32 || AUX == FBL_AUX_ADD_BF16) v[r] += x[r];
+          else if (AUX == FBL_AUX_MUL_DGELU_BF16) v[r] *= dgelu_erf(x[r]);
+          else if (AUX == FBL_AUX_MUL_POS_BF16) v[r] = (x[r] > 0.f) ? v[r] : 0.f;
+          else if (AUX == FBL_AUX_MUL_BF16) v[r] *= x[r];
+        }
+      }
+      const long co = cbase + (long)m * g.ldc + n4;
+      if (full && vec_ok) {
+        if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
+        if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if (g.out_pre) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};
+      } else {
+        for (int r = 0; r < 4; ++r) {
+          if (n4 + r >= g.N) break;
+          if (g.out_f32) g.out_f32[co + r] = v[r];
+          if (g.out_bf16) g.out_bf16[co + r] = f2bf(v[r]);
+          if (g.out_pre) g.out_pre[co + r] = f2bf(pre[r]);
+        }
+      }
+    }
+    }
+  }
+}
+
+// 8-phase 256x256 kernel (gemm8.hip).  Returns 0 when launched, FBL_ERR_ARG for an epilogue combination it does not
+// instantiate (the caller then uses the 2-stage kernel).
+int launch_gemm8(const GemmArgs& g, int act, int aux_kind, dim3 grid, hipStream_t stream);
+bool gemm8_eligible(const GemmArgs& g);
+
+}  // namespace fblgemm

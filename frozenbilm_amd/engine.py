@@ -83,9 +83,8 @@ class Engine:
         # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
         # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
         self.side = torch.cuda.Stream(device=dev)  # (stream priorities were measured: no effect on the interference)
-        # the full-logits GEMM of the forward gets its own stream: on `side` it would sit in front of the first dW
-        # kernels of the backward and every data-parallel bucket would wait 3.7 ms for an output nobody reads
-        self.side_logits = torch.cuda.Stream(device=dev)
+        # reference-faithful switch: fill the full [N, V] logits in every forward even when only the loss is consumed
+        self.eager_logits = os.environ.get("FBL_EAGER_LOGITS", "0") == "1"
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
@@ -294,6 +293,9 @@ class Engine:
             else:
                 full_labels = labels
             full_labels = full_labels.contiguous().view(-1)
+            # The labelled rows are a function of the INPUT only: find them before anything is queued, so the host
+            # synchronisation inside nonzero() waits for the previous step at most, never for this forward.
+            rows_labelled = torch.nonzero(full_labels != -100).view(-1)
         if train:
             m.step_seed += 1
         run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=m.step_seed * 1000003 + 12345,
@@ -302,12 +304,12 @@ class Engine:
                   p_ad=m.adapter_dropout if train else 0.0)
         run.mask = mask.view(-1)
         run.labels = full_labels
+        run.rows = rows_labelled if full_labels is not None else None
         self.refresh_trainable_operands()
         use_ans = bool(m.n_ans) and not mlm
         logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden)
         Vout = self.n_ans if use_ans else self.V
-        res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None,
-               "logits_event": getattr(run, "logits_event", None)}
+        res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None, "run": run}
         if want_hidden:
             res["hidden_states"] = run.hidden_out
         if need_grad and res["logits"] is not None:
@@ -343,11 +345,8 @@ class Engine:
         """y = x + up(drop(relu(down(x))))  (model/adapter.py:33-45) as two epilogue-fused GEMMs."""
         A, Ap = ent["A"], ent["Ap"]
         z = torch.zeros(N, Ap, dtype=BF16, device=self.dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=self.dev)
-        L.gemm(x_bf16, ent["down"], bias=ent["bd"], act=L.ACT_RELU, out_bf16=z, N=A)
-        seed = 0
-        if run.p_ad > 0:
-            seed = run.next_seed()
-            L.dropout_bf16_(z, run.p_ad, seed)
+        seed = run.next_seed() if run.p_ad > 0 else 0
+        L.adapter_down_fwd(x_bf16, ent["down"], ent["bd"], z, A=A, p_drop=run.p_ad, seed=seed)  # ReLU + dropout in the epilogue
         y = torch.empty(N, self.H, dtype=F32, device=self.dev)
         L.gemm(z, ent["up"], bias=ent["bu"], aux=x_f32, aux_kind=L.AUX_ADD_F32, out_f32=y)
         return y, z, seed
@@ -488,12 +487,13 @@ class Engine:
             Vout, table, bias = self.V, self.Eb, self.head_bias
         ldv = _ru(Vout, 64)
         run.Vout = Vout
-        loss_t = None
-        if run.labels is not None and run.save and self.use_side_stream:
-            # Training: the loss only needs the labelled rows.  Their logits are computed first (tiny GEMM) so CE and the
-            # whole backward can start, while the full [N, V] logits tensor -- an OUTPUT of the reference API that no
-            # training caller reads -- is produced concurrently on the side stream (MaskedLMOutput waits on access).
-            rows = torch.nonzero(run.labels != -100).view(-1)
+        run.head_table, run.head_bias, run.ldv = table, bias, ldv
+        if run.labels is not None:
+            # A loss is asked for: it only needs the labelled rows.  Their logits come from a small GEMM so CE (and the
+            # backward) can follow at once; the full [N, V] logits tensor -- an OUTPUT of the reference API that neither
+            # main.py's train_one_epoch nor evaluate reads (main.py:67,139) -- is allocated but only FILLED on first
+            # access (MaskedLMOutput -> fill_logits): 4.4 GB of writes and 3.4 TFLOP per step at the xlarge vocabulary.
+            rows = run.rows
             run.rows_i32 = rows.to(torch.int32)
             R = rows.numel()
             run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
@@ -506,25 +506,23 @@ class Engine:
                 run.row_lse = torch.empty(R, dtype=F32, device=dev)
                 L.ce_fwd(lc, run.labels_c, Vout, run.row_lse, run.loss_acc)
                 run.logits_c = lc
-            loss_t = run.loss_acc[0] / run.loss_acc[1]
-            self.side_logits.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side_logits):
-                logits = torch.empty(N, ldv, dtype=F32, device=dev)
-                L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
-                run.logits_event = torch.cuda.Event()
-                run.logits_event.record(self.side_logits)
-            hl.bf16.record_stream(self.side_logits)
-            run.logits = logits
-            return logits, loss_t
+            loss_t = run.loss_acc[0] / run.loss_acc[1]  # mean over labelled rows (CrossEntropyLoss, :1483-1488)
+            run.logits = torch.empty(N, ldv, dtype=F32, device=dev)
+            run.logits_pending = True
+            if self.eager_logits:
+                self.fill_logits(run)
+            return run.logits, loss_t
         logits = torch.empty(N, ldv, dtype=F32, device=dev)
         L.gemm(hl.bf16, table, bias=bias, out_f32=logits, N=Vout)
         run.logits = logits
-        if run.labels is not None:
-            run.row_lse = torch.empty(N, dtype=F32, device=dev)
-            run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
-            L.ce_fwd(logits, run.labels, Vout, run.row_lse, run.loss_acc)
-            loss_t = run.loss_acc[0] / run.loss_acc[1]  # mean over labelled rows (CrossEntropyLoss, :1483-1488)
-        return logits, loss_t
+        return logits, None
+
+    def fill_logits(self, run):
+        """Full [N, V] logits of a forward that only computed the labelled rows (see _forward); idempotent.  Writes into
+        the storage of the tensor already handed out (and already wired into the autograd node), on the current stream."""
+        if getattr(run, "logits_pending", False):
+            run.logits_pending = False
+            L.gemm(run.head_ln_bf16, run.head_table, bias=run.head_bias, out_f32=run.logits, N=run.Vout)
 
     def _materialize(self, s: Stream, add=None, S=1, out_f32=None, out_bf16=None):
         N, H = s.bf16.shape
@@ -731,18 +729,14 @@ class Engine:
         Vp = _ru(Vout, 64)
         # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)
         if gloss is not None and run.labels is not None:
-            compact = getattr(run, "logits_c", None) is not None or getattr(run, "rows_i32", None) is not None
-            rows = run.rows_i32 if compact else torch.nonzero(run.labels != -100).view(-1).to(torch.int32)
+            rows = run.rows_i32
             R = rows.numel()
             if R > 0:
                 dlog = torch.empty(R, Vp, dtype=BF16, device=dev)
                 # the incoming loss gradient stays on the device (read by the kernel): no host sync at backward start
                 gs = gloss.detach().to(F32) if (isinstance(gloss, torch.Tensor) and gloss.is_cuda) else float(gloss)
-                if compact:  # logits of the labelled rows only (training path)
-                    ar = torch.arange(R, dtype=torch.int32, device=dev)
-                    L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, gs, dlog)
-                else:
-                    L.ce_bwd_rows(run.logits, run.labels, rows, Vout, Vp, run.row_lse, run.loss_acc, gs, dlog)
+                ar = torch.arange(R, dtype=torch.int32, device=dev)  # logits_c holds the labelled rows only
+                L.ce_bwd_rows(run.logits_c, run.labels_c, ar, Vout, Vp, run.row_lse, run.loss_acc, gs, dlog)
                 self._head_bwd(run, rows, dlog, dq)
                 del dlog
         # ---- gradient handed in on the logits themselves (downstream losses): every token row

@@ -24,6 +24,7 @@ SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
                               _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp]),
+    "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -161,6 +162,18 @@ def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, a
                                    sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), int(a_kblock),
                                    _p(kskip_len), int(kskip_steps), _stream())
     _chk(code, "fbl_gemm_bf16_nt")
+
+
+def adapter_down_fwd(x, wd, bias, z, *, A=None, p_drop=0.0, seed=0):
+    """z[M, A] = dropout(relu(x @ wd[:A]^T + bias)): one launch (ReLU and dropout live in the GEMM epilogue)."""
+    _req(x, torch.bfloat16, "x"); _req(wd, torch.bfloat16, "wd"); _req(z, torch.bfloat16, "z")
+    _req(bias, torch.float32, "bias")
+    ldx, ldw, ldz = _rows2d(x, "x"), _rows2d(wd, "wd"), _rows2d(z, "z")
+    M, K = x.shape
+    A = wd.shape[0] if A is None else A
+    assert wd.shape[1] == K and z.shape[0] >= M and z.shape[1] >= A
+    _chk(load().fbl_adapter_down_fwd(_p(x), ldx, _p(wd), ldw, M, A, K, _p(bias), float(p_drop), int(seed), _p(z), ldz,
+                                     _stream()), "fbl_adapter_down_fwd")
 
 
 def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):

@@ -30,9 +30,7 @@ class _AdapterFn(torch.autograd.Function):
         wub = torch.zeros(H, Ap, dtype=torch.bfloat16, device=dev)
         wub[:, :A] = wu.detach().to(torch.bfloat16)
         z = torch.zeros(N, Ap, dtype=torch.bfloat16, device=dev)
-        L.gemm(xb, wdb, bias=bd.detach().float().contiguous(), act=L.ACT_RELU, out_bf16=z, N=A)
-        if p_drop > 0:
-            L.dropout_bf16_(z, p_drop, seed)
+        L.adapter_down_fwd(xb, wdb, bd.detach().float().contiguous(), z, A=A, p_drop=p_drop, seed=seed)
         y = torch.empty(N, H, dtype=torch.float32, device=dev)
         L.gemm(z, wub, bias=bu.detach().float().contiguous(), aux=x2, aux_kind=L.AUX_ADD_F32, out_f32=y)
         ctx.save_for_backward(xb, z, wd, wu)
@@ -87,6 +85,10 @@ class Adapter(nn.Module):
         self.dropout = float(dropout) if dropout else 0.0
         self.apply(self.init_weights)
         self._calls = 0
+        # dropout stream of this instance: torch's seed (args.seed + rank in the reference's main()) and a per-instance
+        # draw, so that adapters do not share masks and data-parallel ranks differ (model/adapter.py:41 draws from the
+        # per-process torch RNG)
+        self._seed_base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) << 16
 
     def init_weights(self, m: nn.Module, std=1e-3):
         """model/adapter.py:23-31: N(0, std) clamped to +-2 std."""
@@ -99,4 +101,4 @@ class Adapter(nn.Module):
         p = self.dropout if self.training else 0.0
         self._calls += 1
         return _AdapterFn.apply(hidden_states, self.down.weight, self.down.bias, self.up.weight, self.up.bias, p,
-                                0x5EED0000 + self._calls)
+                                (self._seed_base + self._calls) & 0xFFFFFFFFFFFF)

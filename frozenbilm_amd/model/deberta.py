@@ -29,19 +29,18 @@ from .config import DebertaV2Config
 class MaskedLMOutput(dict):
     """Attribute + item access (`out.loss`, `out["loss"]`), like transformers' MaskedLMOutput (main.py:67).
 
-    In training the full ``logits`` tensor is produced on a side HIP stream while backward already runs (the loss only
-    needs the labelled rows); the first access makes the current stream wait for it."""
+    When a loss was asked for (``labels`` given) the forward computes only the labelled rows of the prediction head;
+    the full ``logits`` tensor is allocated -- and wired into the autograd graph like the reference's -- but its
+    contents are produced on first access, by any accessor of this mapping (``out.logits``, ``out["logits"]``,
+    ``out[1]``, ``get``, ``values``, ``items``, iteration / ``dict(out)`` / ``**out``)."""
 
-    _logits_event = None
+    _fill = None  # callable that materialises the logits, or None
 
     def _sync_logits(self):
-        ev = self.__dict__.get("_logits_event")
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            lg = super().__getitem__("logits")
-            if lg is not None:
-                lg.record_stream(torch.cuda.current_stream())
-            self.__dict__["_logits_event"] = None
+        fill = self.__dict__.get("_fill")
+        if fill is not None:
+            self.__dict__["_fill"] = None
+            fill()
 
     def __getattr__(self, k):
         try:
@@ -52,10 +51,40 @@ class MaskedLMOutput(dict):
     def __getitem__(self, k):
         if isinstance(k, int):
             self._sync_logits()
-            return [v for v in self.values() if v is not None][k]
+            return [v for v in super().values() if v is not None][k]
         if k == "logits":
             self._sync_logits()
         return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        if k == "logits":
+            self._sync_logits()
+        return super().get(k, default)
+
+    def __iter__(self):  # (also takes dict(out) / {**out} off CPython's fast path, which would bypass __getitem__)
+        self._sync_logits()
+        return super().__iter__()
+
+    def keys(self):
+        self._sync_logits()
+        return super().keys()
+
+    def values(self):
+        self._sync_logits()
+        return super().values()
+
+    def items(self):
+        self._sync_logits()
+        return super().items()
+
+    def copy(self):
+        self._sync_logits()
+        return dict(super().items())
+
+    def pop(self, k, *default):
+        if k == "logits":
+            self._sync_logits()
+        return super().pop(k, *default)
 
 
 class _Node(nn.Module):
@@ -307,7 +336,9 @@ class DebertaV2ForMaskedLM(nn.Module):
         res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states)
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
                              attentions=None)
-        out.__dict__["_logits_event"] = res.get("logits_event")
+        run = res.get("run")
+        if run is not None and getattr(run, "logits_pending", False):
+            out.__dict__["_fill"] = lambda: eng.fill_logits(run)
         if return_dict is False:
             return tuple(v for v in (out["loss"], out["logits"], out["hidden_states"]) if v is not None)
         return out

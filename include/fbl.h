@@ -57,6 +57,15 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len,
                      int kskip_steps, void* stream);
 
+/* Adapter down-projection with the whole bottleneck non-linearity in the GEMM epilogue:
+ *   z[M, A] = dropout_p( relu( x[M,K] . Wd[A,K]^T + bd ) )        (bf16 MFMA, fp32 accumulate, bf16 out)
+ * Dropout is the counter-based one of fbl_dropout_bf16: element (m, a) is keyed by (seed, m*ldz + a), dropped elements
+ * are exactly 0, kept ones scaled by 1/(1-p); p_drop == 0 -> plain ReLU.  K % 64 == 0, ldx/ldw % 8 == 0.
+ * The backward needs no mask: d/dz passes where z > 0, scaled by 1/(1-p) (FBL_AUX_MUL_POS_BF16 with alpha).
+ * ref: model/adapter.py:38-41 (down -> ReLU -> nn.Dropout). */
+int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, int64_t ldw, int M, int A, int K,
+                         const float* bias, float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream);
+
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
  * (splitk_ws >= splitk*M*roundup(N,4) floats, required).  M, N, lda, ldb multiples of 8; K arbitrary.
