@@ -227,6 +227,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   }
   // every fragment read of the ring retired (each wave waited lgkmcnt(0) before its last barriers): the epilogue may
   // reuse the LDS
+  if constexpr (VAR & 4) {  // experiment: main loop only (accumulators kept alive, nothing stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   const int ec = (lane & 15) * 4;
   gemm_epilogue<ACT, AUX, false, 8>(g, smem, wave, lane, acc, m0 + wm * 64, 128, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
                                     0, 0);
@@ -250,6 +257,7 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     if (var == 0) FBL_G8_LAUNCH(0);
     else if (var == 1) FBL_G8_LAUNCH(1);
     else if (var == 2) FBL_G8_LAUNCH(2);
+    else if (var == 7) FBL_G8_LAUNCH(7);
     else FBL_G8_LAUNCH(3);
   } else {
     FBL_G8_LAUNCH(3);

@@ -1,6 +1,8 @@
 // Pieces shared by the bf16 MFMA GEMM kernels of libfbl (gemm.hip: 2-stage tiles; gemm8.hip: 8-phase 256x256 tile):
 // the argument block, the LDS-DMA helper, the XCD-aware tile mapping and the fused epilogue.
 #pragma once
+#include <type_traits>
+
 #include "fbl_common.h"
 #include "../../include/fbl.h"
 
@@ -114,7 +116,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
         for (int ni = 0; ni < 4; ++ni)
           *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
       }
+    // per-row scale of the slab, loaded up front: a global load inside the row loop would make every iteration wait
+    // (vmcnt is one in-order counter for loads AND stores) for all stores of the previous rows to be acknowledged
+    float rsv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) rsv[it] = 1.0f;
+    if (g.rowscale) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        if (it < cnt * 4) rsv[it] = g.rowscale[min(mslab + it * 4 + er, g.M - 1)];
+    }
+    // Every global load of the slab (aux operand, row scales) is COMPLETE before the first store: the stores below sit in
+    // branches, so the compiler cannot count them and would otherwise wait with vmcnt(0) in every row iteration -- i.e.
+    // for the acknowledgement of all earlier stores -- to be sure a load issued up here has landed.
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      asm volatile("" : "+v"(rsv[it]));
+      if (AUX_F32) asm volatile("" : "+v"(xa32[AUX_F32 ? it : 0]));
+      if (AUX != FBL_AUX_NONE && !AUX_F32) asm volatile("" : "+v"(xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? it : 0]));
+    }
     if (n4 < g.N) {
+    // element offsets of this lane's first row of the slab; the per-iteration part (4*it rows) is wave-uniform
+    const long er_c = cbase + (long)(mslab + er) * g.ldc + n4;
+    const long er_x = xbase + (long)(mslab + er) * g.ld_aux + n4;
+    // (two copies of the row loop, selected by the wave-uniform aux_fast: the slow path loads aux inside the loop, and a
+    //  join of "maybe a load is pending" with the fast path would put a vmcnt(0) into every iteration of both)
+    auto row_loop = [&](auto fastc) {
+    constexpr bool AUXFAST = decltype(fastc)::value;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       if (it >= cnt * 4) break;
@@ -122,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       const int m = mslab + row;
       if (m >= g.M) continue;
       const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
-      const float rs = g.rowscale ? g.rowscale[m] : 1.0f;
+      const float rs = rsv[it];
       float v[4], pre[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (a4[r] * g.alpha + bv[r]) * rs;
@@ -148,17 +176,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
           v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)m * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
       }
       if (AUX != FBL_AUX_NONE) {
-        const long ao = xbase + (long)m * g.ld_aux + n4;
+        const long ao = er_x + (long)(it * 4) * g.ld_aux;
         float x[4] = {0.f, 0.f, 0.f, 0.f};
         if (AUX == FBL_AUX_ADD_F32) {
-          if (aux_fast) {
+          if (AUXFAST) {
             const f32x4 t = xa32[AUX_F32 ? it : 0];
             x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
           } else {
             for (int r = 0; r < 4 && n4 + r < g.N; ++r) x[r] = ((const float*)g.aux)[ao + r];
           }
         } else {
-          if (aux_fast) {
+          if (AUXFAST) {
             const bf16x4 t = xa16[(AUX != FBL_AUX_NONE && !AUX_F32) ? it : 0];
             x[0] = bf2f(t[0]); x[1] = bf2f(t[1]); x[2] = bf2f(t[2]); x[3] = bf2f(t[3]);
           } else {
@@ -173,7 +201,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
           else if (AUX == FBL_AUX_MUL_BF16) v[r] *= x[r];
         }
       }
-      const long co = cbase + (long)m * g.ldc + n4;
+      const long co = er_c + (long)(it * 4) * g.ldc;
       if (full && vec_ok) {
         if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
         if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -187,6 +215,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
         }
       }
     }
+    };
+    if (AUX != FBL_AUX_NONE && aux_fast) row_loop(std::true_type{});
+    else row_loop(std::false_type{});
     }
   }
 }
