@@ -298,7 +298,7 @@ class Engine:
             rows_labelled = torch.nonzero(full_labels != -100).view(-1)
         if train:
             m.step_seed += 1
-        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=m.step_seed * 1000003 + 12345,
+        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=m.dropout_seed_base(),
                   p_hid=self.cfg.hidden_dropout_prob if train else 0.0,
                   p_att=self.cfg.attention_probs_dropout_prob if train else 0.0,
                   p_ad=m.adapter_dropout if train else 0.0)

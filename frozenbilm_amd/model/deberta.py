@@ -223,7 +223,9 @@ class DebertaV2ForMaskedLM(nn.Module):
         emb = self._module("deberta.embeddings")
         emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
         self._engine = None
+        self._reducer = None  # parallel.GradReducer attached to this model (survives engine rebuilds)
         self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
+        self._seed_salt = None  # torch seed (args.seed + rank in the reference's main()) and rank, fixed at first use
 
     # ---------------------------------------------------------------- module tree helpers
     def _module(self, dotted: str) -> nn.Module:
@@ -307,7 +309,25 @@ class DebertaV2ForMaskedLM(nn.Module):
             from ..engine import Engine
 
             self._engine = Engine(self)
+            if self._reducer is not None:
+                self._reducer.rebind(self._engine)
         return self._engine
+
+    def dropout_seed_base(self) -> int:
+        """Seed of this training step's dropout sites.  The reference draws its masks from the per-process torch RNG,
+        seeded with args.seed + rank (main.py:161-165): mixing torch.initial_seed() and the rank gives every data-parallel
+        rank and every differently seeded run its own mask stream; ``step_seed`` (saved in checkpoints) advances it."""
+        if self._seed_salt is None:
+            rank = 0
+            try:
+                import torch.distributed as dist
+
+                if dist.is_available() and dist.is_initialized():
+                    rank = dist.get_rank()
+            except Exception:
+                rank = 0
+            self._seed_salt = ((torch.initial_seed() & 0xFFFFFFFF) * 2654435761 + rank * 40503 + 12345) & 0xFFFFFFFFFFFF
+        return (self.step_seed * 1000003 + self._seed_salt) & 0xFFFFFFFFFFFF
 
     def forward(
         self,
@@ -337,6 +357,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
                              attentions=None)
         run = res.get("run")
+        out.__dict__["_run"] = run  # (tests read the saved bottleneck activations through this)
         if run is not None and getattr(run, "logits_pending", False):
             out.__dict__["_fill"] = lambda: eng.fill_logits(run)
         if return_dict is False:

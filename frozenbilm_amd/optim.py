@@ -32,9 +32,14 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None, clip_max_norm: float = 0.0, grad_scale: float = 1.0):
         eng = self.model.engine()
         flat, g = eng.flat, eng.flat_grad
-        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+        if self._m is None:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
+            self._ss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        elif self._m.numel() != flat.numel():
+            raise RuntimeError("the trainable set changed size under a live optimizer state")
+        elif self._m.device != flat.device:  # the model moved: the moments follow it
+            self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)
             self._ss = torch.zeros(1, dtype=torch.float32, device=flat.device)
         grp = self.param_groups[0]
         self._step += 1
@@ -51,11 +56,57 @@ class FusedAdam(torch.optim.Optimizer):
         """global L2 norm of the last clipped step's gradients (device scalar)"""
         return self._ss.sqrt() if self._ss is not None else torch.zeros(())
 
+    # ---- checkpoints: torch.optim.Adam's schema, so files written by the reference (main.py:290-300 saves
+    # optimizer.state_dict() of torch.optim.Adam over [p for p in model.parameters() if p.requires_grad], main.py:182-188)
+    # resume here and files written here resume there.  Parameter i of the schema is the i-th trainable parameter in
+    # model.parameters() order; its moments are the slice of the flat m / v buffers at that parameter's offset.
+    def _slices(self, eng):
+        by_id = {id(eng.named[n]): (eng.offsets[n], eng.named[n].numel(), tuple(eng.named[n].shape)) for n in eng.order}
+        return [by_id[id(p)] for p in self.param_groups[0]["params"]]
+
     def state_dict(self):
-        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": [
-            {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        eng = self.model.engine()
+        state = {}
+        if self._m is not None and self._step > 0:
+            for i, (o, k, shape) in enumerate(self._slices(eng)):
+                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": self._m[o:o + k].view(shape).clone(),
+                            "exp_avg_sq": self._v[o:o + k].view(shape).clone()}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(len(g["params"])))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._step, self._m, self._v = sd["step"], sd["m"], sd["v"]
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        eng = self.model.engine()
+        flat = eng.flat
+        m = torch.zeros_like(flat)
+        v = torch.zeros_like(flat)
+        if "state" in sd:  # torch.optim.Adam schema (reference-written or ours)
+            sl = self._slices(eng)
+            steps = set()
+            for i, st in sd["state"].items():
+                i = int(i)
+                if i >= len(sl):
+                    raise ValueError(f"optimizer state for parameter {i}, but only {len(sl)} trainable parameters")
+                o, k, shape = sl[i]
+                if st["exp_avg"].numel() != k or st["exp_avg_sq"].numel() != k:
+                    raise ValueError(f"optimizer state {i}: {tuple(st['exp_avg'].shape)} does not match parameter {shape}")
+                m[o:o + k].copy_(st["exp_avg"].reshape(-1).to(flat.device, flat.dtype))
+                v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1).to(flat.device, flat.dtype))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused update keeps one")
+            self._step = steps.pop() if steps else 0
+        else:  # flat schema of earlier builds: {"step", "m", "v"}
+            if sd["m"] is not None:
+                if sd["m"].numel() != flat.numel() or sd["v"].numel() != flat.numel():
+                    raise ValueError("flat optimizer state does not match the trainable buffer")
+                m.copy_(sd["m"].to(flat.device, flat.dtype))
+                v.copy_(sd["v"].to(flat.device, flat.dtype))
+            self._step = int(sd["step"])
+        self._m, self._v = m, v
+        self._ss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v_ for k, v_ in s_.items() if k != "params"})

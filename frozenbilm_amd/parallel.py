@@ -30,10 +30,23 @@ class GradReducer:
 
     @classmethod
     def attach(cls, model, group=None, **kw) -> "GradReducer":
+        """Attach to ``model`` (not to one Engine instance): the model rebuilds its engine -- new flat buffers -- after
+        load_state_dict / .to() / set_answer_embeddings, which in the reference flow all happen AFTER the optimizer and
+        the reducer are created (main.py:182 vs :235, videoqa.py:381); ``model.engine()`` re-binds the reducer then."""
         eng = model.engine()
         red = cls(eng.flat_grad, eng.bucket_ends, group=group, **kw)
         eng.reducer = red
+        model._reducer = red
         return red
+
+    def rebind(self, eng) -> None:
+        """Point the reducer at a freshly built engine's flat gradient buffer and bucket boundaries."""
+        if self.pending or self.cursor:
+            raise RuntimeError("GradReducer.rebind in the middle of a gradient exchange")
+        self.flat_grad = eng.flat_grad
+        self.bucket_ends = dict(eng.bucket_ends)
+        self.launched = []
+        eng.reducer = self
 
     @contextlib.contextmanager
     def accumulate(self):

@@ -15,8 +15,11 @@ def checkpoint_dict(model, optimizer, epoch, args, trainable_only: bool = False)
     if trainable_only:
         keep = {n for n, p in model.named_parameters() if p.requires_grad}
         sd = {k: v for k, v in sd.items() if k in keep}
-    return {"model": sd, "optimizer": optimizer.state_dict() if optimizer is not None else None, "epoch": epoch,
-            "args": args}
+    ck = {"model": sd, "optimizer": optimizer.state_dict() if optimizer is not None else None, "epoch": epoch,
+          "args": args}
+    if hasattr(model, "step_seed"):  # position of the dropout stream (an extra key: the reference's loader ignores it)
+        ck["fbl"] = {"step_seed": int(model.step_seed)}
+    return ck
 
 
 def save_checkpoint(model, optimizer, epoch, args, path, trainable_only: bool = False):
@@ -37,4 +40,6 @@ def load_checkpoint(model, path, optimizer=None, resume: bool = False, map_locat
     if resume and optimizer is not None and ckpt.get("optimizer") is not None:
         optimizer.load_state_dict(ckpt["optimizer"])
         start_epoch = ckpt["epoch"] + 1
+        if hasattr(model, "step_seed") and isinstance(ckpt.get("fbl"), dict):
+            model.step_seed = int(ckpt["fbl"].get("step_seed", model.step_seed))
     return ckpt, start_epoch

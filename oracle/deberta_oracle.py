@@ -96,8 +96,35 @@ def rel_index_by_delta(S: int, cfg: OracleConfig) -> np.ndarray:
 # --------------------------------------------------------------------------
 # small ops
 # --------------------------------------------------------------------------
+# Optional "bf16 operand" mode (test infrastructure): every matrix-multiply operand is rounded to bfloat16 on the way
+# in (straight-through in backward), accumulation stays fp32 -- the arithmetic contract of the HIP path (bf16 MFMA
+# operands, fp32 accumulators, fp32 residual stream / LayerNorm / softmax).  With the same rounding the ReLU gates of
+# the adapters and the GELU arguments agree with the GPU's except at exact ties, so gradient parity can be held to a
+# few per cent instead of the 25 % a gate flip costs against the pure fp32 math.  Default off: the fp32 mode is what
+# the golden vectors captured from the reference pin.
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+    def __enter__(self):
+        global _BF16_OPERANDS
+        self._prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_OPERANDS
+        _BF16_OPERANDS = self._prev
+        return False
+
+
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    if not _BF16_OPERANDS:
+        return x
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
 def _lin(x: torch.Tensor, P: Params, name: str) -> torch.Tensor:
-    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    return F.linear(_rb(x), _rb(P[name + ".weight"]), P.get(name + ".bias"))
 
 
 def _ln(x: torch.Tensor, P: Params, name: str, eps: float) -> torch.Tensor:
@@ -109,12 +136,39 @@ def gelu_erf(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
+# Optional ReLU-gate override (test infrastructure): inside ``with adapter_gates(masks)`` every adapter call consumes the
+# next 0/1 mask of the list (execution order: per layer execution the attention-output adapter, then the FFN-output one)
+# and uses it in place of relu'(.) -- forward and backward.  A test takes the masks from the bottleneck activations the
+# GPU run saved (z > 0), which removes the one discontinuity through which rounding noise becomes an O(10 %) difference
+# in d(down.weight): what is left must agree to rounding.
+_GATES = None
+
+
+class adapter_gates:
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _GATES
+        self._prev, _GATES = _GATES, iter(self.masks)
+        return self
+
+    def __exit__(self, *exc):
+        global _GATES
+        _GATES = self._prev
+        return False
+
+
 def adapter(x: torch.Tensor, P: Params, prefix: str, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
     """model/adapter.py:33-45 with default flags: x + up(drop(relu(down(x)))).
 
     ``drop`` (optional) is a multiplicative keep/scale mask [.., A] standing in for nn.Dropout.
     """
-    z = torch.relu(_lin(x, P, prefix + ".down"))
+    pre = _lin(x, P, prefix + ".down")
+    if _GATES is not None:
+        z = pre * next(_GATES).to(pre.dtype).view(pre.shape)
+    else:
+        z = torch.relu(pre)
     if drop is not None:
         z = z * drop
     return x + _lin(z, P, prefix + ".up")
@@ -145,16 +199,16 @@ def disentangled_attention(
     nh, d = cfg.num_attention_heads, cfg.head_dim
     B, S, H = hidden.shape
     q_in = hidden if query_states is None else query_states
-    q = _split_heads(_lin(q_in, P, prefix + ".query_proj"), nh)  # :757-759
-    k = _split_heads(_lin(hidden, P, prefix + ".key_proj"), nh)  # :760-762
-    v = _split_heads(_lin(hidden, P, prefix + ".value_proj"), nh)  # :763-765
+    q = _rb(_split_heads(_lin(q_in, P, prefix + ".query_proj"), nh))  # :757-759
+    k = _rb(_split_heads(_lin(hidden, P, prefix + ".key_proj"), nh))  # :760-762
+    v = _rb(_split_heads(_lin(hidden, P, prefix + ".value_proj"), nh))  # :763-765
     scale = math.sqrt(d * 3)  # :769-776 scale_factor = 1 + c2p + p2c
     scores = torch.bmm(q, k.transpose(1, 2)) / scale  # :777
 
     span = cfg.att_span
     rel = torch.from_numpy(rel_pos).long()
-    pos_q = _split_heads(_lin(rel_emb[None], P, prefix + ".query_proj"), nh)  # :848-850 [nh,2span,d]
-    pos_k = _split_heads(_lin(rel_emb[None], P, prefix + ".key_proj"), nh)  # :851-853
+    pos_q = _rb(_split_heads(_lin(rel_emb[None], P, prefix + ".query_proj"), nh))  # :848-850 [nh,2span,d]
+    pos_k = _rb(_split_heads(_lin(rel_emb[None], P, prefix + ".key_proj"), nh))  # :851-853
     pos_q = pos_q.repeat(B, 1, 1)
     pos_k = pos_k.repeat(B, 1, 1)
     # c2p :870-881
@@ -173,7 +227,7 @@ def disentangled_attention(
     rmask = ~(mask4d.bool())
     probs = torch.softmax(scores.masked_fill(rmask, float("-inf")), -1)
     probs = probs.masked_fill(rmask, 0.0)
-    ctx = torch.bmm(probs.view(B * nh, S, S), v)  # :797-802
+    ctx = torch.bmm(_rb(probs.view(B * nh, S, S)), v)  # :797-802
     ctx = ctx.view(B, nh, S, d).permute(0, 2, 1, 3).reshape(B, S, H)  # :803-814
     if return_probs:
         return ctx, probs
@@ -210,7 +264,7 @@ def conv_layer(emb: torch.Tensor, resid: torch.Tensor, input_mask: torch.Tensor,
     """model/deberta.py:395-419 ConvLayer (conv_act = gelu, groups = 1), eval mode."""
     pre = "deberta.encoder.conv"
     pad = (cfg.conv_kernel_size - 1) // 2
-    c = F.conv1d(emb.permute(0, 2, 1).contiguous(), P[pre + ".conv.weight"], P[pre + ".conv.bias"], padding=pad)
+    c = F.conv1d(_rb(emb.permute(0, 2, 1).contiguous()), _rb(P[pre + ".conv.weight"]), P[pre + ".conv.bias"], padding=pad)
     c = c.permute(0, 2, 1).contiguous()
     c = c.masked_fill((1 - input_mask).bool()[..., None], 0.0)
     out = _ln(resid + gelu_erf(c), P, pre + ".LayerNorm", cfg.layer_norm_eps)
@@ -266,7 +320,7 @@ def lm_head(x: torch.Tensor, table: torch.Tensor, bias: torch.Tensor, P: Params,
     pre = "lm_predictions.lm_head"
     h = gelu_erf(_lin(x, P, pre + ".dense"))
     h = _ln(h, P, pre + ".LayerNorm", cfg.layer_norm_eps)
-    return h @ table.t() + bias
+    return _rb(h) @ _rb(table).t() + bias
 
 
 def answer_embeddings(a2tok: torch.Tensor, P: Params, cfg: OracleConfig) -> torch.Tensor:

@@ -627,6 +627,137 @@ def g13_main_loops(deberta, ref_main):
     npz("G13_main_loops", **out)
 
 
+XL_GRAD_FULL = ("deberta.embeddings.linear_video.bias", "deberta.encoder.LayerNorm.weight", "deberta.encoder.LayerNorm.bias",
+                "deberta.embeddings.LayerNorm.weight", "deberta.embeddings.LayerNorm.bias",
+                "lm_predictions.lm_head.LayerNorm.weight", "lm_predictions.lm_head.LayerNorm.bias")
+XL_GRAD_LAYERS = (0, 12, 23)
+
+
+def xl_grad_slices(name, g):
+    """What G6b keeps of one xlarge gradient tensor: small tensors whole, matrices as a strided slice."""
+    if g.dim() == 1:
+        return g
+    return g[::4, ::8].contiguous()
+
+
+def g6b_xlarge_backward(deberta):
+    """True xlarge dims (24 layers, H=1536), eval-mode math, B=2, S=266: the reference's own BACKWARD.  Stored: the
+    Frobenius norm of every trainable gradient (298 tensors), full vectors / strided slices of linear_video, the three
+    stand-alone LayerNorms and everything trainable in layers 0, 12 and 23, loss and a logits slice."""
+    from oracle.deberta_oracle import OracleConfig, synth_params
+
+    cfg = OracleConfig()
+    P = synth_params(cfg, seed=0)
+    m = build_ref_model(deberta, cfg, P)
+    batch = synth_batch(cfg, B=2, L=256, seed=67)
+    out = m(**batch)
+    out.loss.backward()
+    names, norms, keep = [], [], {}
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, n
+        names.append(n)
+        norms.append(float(p.grad.double().norm()))
+        layer_hit = any(n.startswith(f"deberta.encoder.layer.{i}.") for i in XL_GRAD_LAYERS)
+        if n in XL_GRAD_FULL or layer_hit or "linear_video.weight" in n or n.startswith("deberta.encoder.conv."):
+            keep["grad." + n] = xl_grad_slices(n, p.grad)
+    lg = out.logits.detach()
+    npz("G6b_xlarge_backward", seed=np.array([0]), batch_seed=np.array([67]), loss=out.loss.detach(),
+        logits_slice=lg[:, ::19, ::997].contiguous(), names=np.array(names), norms=np.array(norms, dtype=np.float64), **keep)
+
+
+def g14_g15_xlarge_downstream(deberta):
+    """True xlarge dims for the two downstream configurations (eval forward only):
+    G14 = cfg 5 (mc.py): S = 512 (T=10 + L=502), Yes/No answer head (n_ans=2), one candidate text per sample, B=2;
+    G15 = cfg 4 (videoqa.py): n_ans = 1000 answer table from set_answer_embeddings, one [MASK] per row, top-10 ids."""
+    from oracle.deberta_oracle import OracleConfig, synth_params
+
+    cfg = OracleConfig(n_ans=1000)
+    P = synth_params(cfg, seed=0)
+    m = build_ref_model(deberta, cfg, P)
+    g = torch.Generator().manual_seed(150)
+    a2tok = torch.randint(5, cfg.vocab_size, (1000, 5), generator=g)
+    alen = torch.randint(1, 6, (1000,), generator=g)
+    a2tok = a2tok * (torch.arange(5)[None] < alen[:, None])
+    m.set_answer_embeddings(a2tok)
+    MASK = 128000  # [MASK] of the deberta-v2 vocabulary
+    batch = synth_batch(cfg, B=2, L=256, seed=151)
+    batch.pop("labels")
+    tlen = batch["attention_mask"].sum(1)
+    mpos = torch.stack([torch.randint(1, int(t), (1,), generator=g) for t in tlen]).view(-1)
+    batch["input_ids"][torch.arange(2), mpos] = MASK
+    with torch.no_grad():
+        lg = m(**batch)["logits"]
+    rows = lg[:, cfg.max_feats:][batch["input_ids"] == MASK]  # [2, 1000]   (videoqa.py:164-168)
+    probs = rows.softmax(-1)
+    npz("G15_xlarge_videoqa", seed=np.array([0]), batch_seed=np.array([151]), a2tok_seed=np.array([150]), mask_id=np.array([MASK]),
+        mask_pos=mpos, mask_logits=rows, mask_probs=probs, top10=probs.topk(10, -1).indices, top10_probs=probs.topk(10, -1).values,
+        logits_slice=lg[:, ::19, ::97].contiguous())
+    # ---- cfg 5: the same model re-headed to the 2-answer table (mc.py:281-305), S = 512
+    a2 = torch.tensor([[2748, 0], [1302, 0]])
+    m.set_answer_embeddings(a2)
+    b5 = synth_batch(cfg, B=2, L=502, seed=141)
+    b5.pop("labels")
+    tlen = b5["attention_mask"].sum(1)
+    mpos5 = torch.stack([torch.randint(1, int(t), (1,), generator=g) for t in tlen]).view(-1)
+    b5["input_ids"][torch.arange(2), mpos5] = MASK
+    with torch.no_grad():
+        lg5 = m(**b5)["logits"]  # [2, 512, 2]
+    score = lg5[:, cfg.max_feats:][b5["input_ids"] == MASK].softmax(-1)[:, 0]  # mc.py:166-172
+    npz("G14_xlarge_mc", seed=np.array([0]), batch_seed=np.array([141]), a2tok=a2, mask_id=np.array([MASK]), mask_pos=mpos5,
+        logits=lg5, score=score)
+
+
+def g16_checkpoint(deberta, ref_main):
+    """A checkpoint WRITTEN BY THE REFERENCE: main.py's epoch (train_one_epoch with torch.optim.Adam) followed by the
+    save_on_master(...) call of main.py:290-300 through the reference's own util/dist.py, on the tiny model.  Also stored:
+    the trainable-parameter order (the index space of the optimizer state), what the reference computes after loading the
+    file again (eval loss) and what one more resumed training epoch does to a few parameters."""
+    import argparse as _ap
+    import json
+    from oracle.deberta_oracle import synth_params
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_videotext_batches
+
+    spec = importlib.util.spec_from_file_location("ref_util_dist", os.path.join(REF, "util/dist.py"))
+    rdist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rdist)
+    cfg = _tiny_cfg(max_feats=4, vocab_size=300, max_position_embeddings=128)
+    P = synth_params(cfg, seed=22, std=0.08, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    zero_dropout(m)
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videotext_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, 3, 6, seed=32)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95))
+    torch.manual_seed(9)
+    ref_main.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device("cpu"), 0, args, 0.1)
+    path = os.path.join(OUT, "G16_reference_checkpoint.pth")
+    ns = _ap.Namespace(lr=1e-3, epochs=2, beta1=0.9, beta2=0.95, clip_max_norm=0.1)
+    rdist.save_on_master({"model": m.state_dict(), "optimizer": opt.state_dict(), "epoch": 0, "args": ns}, path)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KB)")
+    order = [n for n, p in m.named_parameters() if p.requires_grad]
+    # what the reference does with the file (main.py:235-243): a fresh model + optimizer, load, evaluate, resume one epoch
+    m2 = build_ref_model(deberta, cfg, synth_params(cfg, seed=23, std=0.08))
+    zero_dropout(m2)
+    opt2 = torch.optim.Adam([p for p in m2.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.95))
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    m2.load_state_dict(ck["model"], strict=False)
+    opt2.load_state_dict(ck["optimizer"])
+    torch.manual_seed(10)
+    ev = ref_main.evaluate(m2, tok, ListLoader(batches), torch.device("cpu"), args)
+    before = _trainable_state(m2)
+    torch.manual_seed(11)
+    m2.train()
+    tr = ref_main.train_one_epoch(m2, tok, ListLoader(batches), opt2, torch.device("cpu"), 1, args, 0.1)
+    after = _trainable_state(m2)
+    out = {"trainable_order": np.array(order), "eval_stats": np.array(json.dumps({k: float(v) for k, v in ev.items()})),
+           "resume_train_stats": np.array(json.dumps({k: float(v) for k, v in tr.items()}))}
+    for key in ("deberta.embeddings.linear_video.weight", "deberta.encoder.layer.1.output.adapter.up.weight",
+                "deberta.encoder.layer.0.attention.output.adapter.down.weight", "deberta.encoder.LayerNorm.weight"):
+        out[f"resume_delta/{key}"] = after[key] - before[key]
+    npz("G16_checkpoint_meta", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -648,11 +779,14 @@ def main():
         "G11": lambda: g11_mc(deberta, load_downstream()[1]),
         "G12": g12_dataset,
         "G13": lambda: g13_main_loops(deberta, load_downstream()[2]),
+        "G6b": lambda: g6b_xlarge_backward(deberta),
+        "G14": lambda: g14_g15_xlarge_downstream(deberta),  # writes G14 and G15
+        "G16": lambda: g16_checkpoint(deberta, load_downstream()[2]),
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):
             continue
-        if k == "G6" and args.skip_xl:
+        if k in ("G6", "G6b", "G14") and args.skip_xl:
             continue
         fn()
 

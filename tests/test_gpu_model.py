@@ -366,3 +366,288 @@ def test_full_size_backward_linearity_xlarge():
         rel = (g2 - 2 * g1).norm().item() / (2 * g1.norm().item() + 1e-30)
         worst = max(worst, rel)
     assert worst < 2e-3, worst
+
+
+# ------------------------------------------------------------------------------------------------ round-2 parity pins
+def _rel_fro(a, b):
+    return (a - b).norm().item() / max(b.norm().item(), 1e-12)
+
+
+def test_gradients_vs_bf16_operand_oracle_tight():
+    """Every trainable gradient against the oracle run with the HIP path's arithmetic contract (matrix-multiply operands
+    rounded to bf16, fp32 accumulation: oracle.bf16_operands) AND the ReLU gates the GPU run took (oracle.adapter_gates,
+    read from the saved bottleneck activations).  That removes the one discontinuity through which rounding noise turns
+    into a 10 % difference of d(adapter.down): every gradient, adapter.down included, must then agree to a few per cent
+    -- a 10 % systematic error in dW_down, which the 25 % bound against the pure-fp32 reference cannot see, fails here."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = synth_batch(cfg, B=8, L=120, seed=7)
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    out = m(**to_dev(batch))
+    # the ReLU gates the GPU run actually took (saved bottleneck activations z > 0), in execution order
+    gates = []
+    for sv in out.__dict__["_run"].layers:
+        gates += [(sv.z1[:, : cfg.hidden_size // cfg.ds_factor_attn] > 0).cpu(), (sv.z2[:, : cfg.hidden_size // cfg.ds_factor_ff] > 0).cpu()]
+    out.loss.backward()
+    with O.bf16_operands(), O.adapter_gates([g_.view(8, -1, g_.shape[-1]) for g_ in gates]):
+        ref = O.forward(P, cfg, **batch)
+        ref["loss"].backward()
+    assert abs(out.loss.item() - ref["loss"].item()) < 5e-3
+    assert (out.logits.float().cpu() - ref["logits"]).abs().max().item() < 3e-2
+    worst = sorted(((round(_rel_fro(p.grad.float().cpu(), P[n].grad), 4), n) for n, p in m.named_parameters() if p.requires_grad),
+                   reverse=True)
+    print("worst relative Frobenius grad errors vs the bf16-operand oracle:", worst[:8])
+    assert worst[0][0] < 2e-2, worst[:8]  # measured: 0.7 % worst, adapter.down included
+
+
+@pytest.mark.slow
+def test_xlarge_backward_golden(golden):
+    """G6b: the reference's own backward at true xlarge dims (24 layers, H=1536, B=2, S=266): norms of all 298 trainable
+    gradients and the stored full vectors / strided slices (linear_video, the stand-alone LayerNorms, everything trainable
+    in layers 0, 12, 23, conv LayerNorm)."""
+    from tests.golden.make_goldens import xl_grad_slices
+
+    g = golden("G6b_xlarge_backward", raw=True)
+    cfg = O.OracleConfig()
+    P = O.synth_params(cfg, seed=0)
+    m = build(cfg, P)
+    del P
+    batch = synth_batch(cfg, B=2, L=256, seed=67)
+    out = m(**to_dev(batch))
+    out.loss.backward()
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-2
+    sl = out.logits[:, ::19, ::997].float().cpu()
+    assert (sl - torch.from_numpy(g["logits_slice"])).abs().max().item() < 5e-2
+    names = [str(n) for n in g["names"]]
+    got = {n: p.grad.float().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    assert sorted(names) == sorted(got)
+    norm_err = sorted(((abs(got[n].double().norm().item() - r) / max(r, 1e-30), n) for n, r in zip(names, g["norms"])), reverse=True)
+    print("worst gradient-norm errors:", [(round(e, 4), n) for e, n in norm_err[:6]])
+    assert norm_err[0][0] < 0.04, norm_err[:6]  # measured: 1.9 % worst (an adapter.down tensor), < 1 % for the rest
+    bad, worst = [], []
+    for k in g:
+        if not k.startswith("grad."):
+            continue
+        n = k[5:]
+        ref = torch.from_numpy(g[k])
+        mine = xl_grad_slices(n, got[n])
+        fro = _rel_fro(mine, ref)
+        worst.append((round(fro, 4), n))
+        # adapter.down: ReLU-gate flips against the pure-fp32 reference (measured <= 12.5 %; the gate-matched test above
+        # holds the same tensors to 2 %); everything else measured <= 3.7 %
+        if fro > (0.2 if "adapter.down" in n else 5e-2):
+            bad.append((n, round(fro, 4)))
+    worst.sort(reverse=True)
+    print("worst relative Frobenius errors on the stored slices:", worst[:8])
+    assert not bad, bad[:8]
+
+
+@pytest.mark.slow
+def test_xlarge_downstream_goldens(golden):
+    """G15 (cfg 4: n_ans = 1000 answer head, one [MASK] row per sample, top-10 ids) and G14 (cfg 5: S = 512, Yes/No head)
+    at true xlarge dims, against the reference's outputs."""
+    g15, g14 = golden("G15_xlarge_videoqa"), golden("G14_xlarge_mc")
+    cfg = O.OracleConfig(n_ans=1000)
+    P = O.synth_params(cfg, seed=0)
+    m = build(cfg, P)
+    del P
+    gen = torch.Generator().manual_seed(150)
+    a2tok = torch.randint(5, cfg.vocab_size, (1000, 5), generator=gen)
+    alen = torch.randint(1, 6, (1000,), generator=gen)
+    a2tok = a2tok * (torch.arange(5)[None] < alen[:, None])
+    m.set_answer_embeddings(a2tok.to(DEV))
+    MASK = int(g15["mask_id"])
+    batch = synth_batch(cfg, B=2, L=256, seed=151)
+    batch.pop("labels")
+    batch["input_ids"][torch.arange(2), g15["mask_pos"]] = MASK
+    with torch.no_grad():
+        lg = m(**to_dev(batch)).logits.float().cpu()
+    rows = lg[:, cfg.max_feats:][batch["input_ids"] == MASK]
+    assert (rows - g15["mask_logits"]).abs().max().item() < 5e-2
+    assert (lg[:, ::19, ::97] - g15["logits_slice"]).abs().max().item() < 5e-2
+    probs = rows.softmax(-1)
+    assert (probs - g15["mask_probs"]).abs().max().item() < 2e-3
+    # token indices: the top-10 answer ids agree at every rank the reference separates from both neighbours by more than
+    # twice the logit tolerance, and the top-10 sets overlap in all but near-tied entries
+    ref_l = g15["mask_logits"].sort(-1, descending=True).values
+    top = probs.topk(10, -1).indices
+    checked = 0
+    for b in range(2):
+        for r in range(10):
+            if (r == 0 or ref_l[b, r - 1] - ref_l[b, r] > 0.1) and ref_l[b, r] - ref_l[b, r + 1] > 0.1:
+                assert top[b, r] == g15["top10"][b, r], (b, r)
+                checked += 1
+        assert len(set(top[b].tolist()) & set(g15["top10"][b].tolist())) >= 8
+    print("top-10 ranks checked exactly:", checked)
+    # ---- cfg 5 regime on the same weights: 2-answer head, S = 512
+    m.set_answer_embeddings(g14["a2tok"].to(DEV))
+    b5 = synth_batch(cfg, B=2, L=502, seed=141)
+    b5.pop("labels")
+    b5["input_ids"][torch.arange(2), g14["mask_pos"]] = MASK
+    with torch.no_grad():
+        lg5 = m(**to_dev(b5)).logits.float().cpu()
+    assert lg5.shape == (2, 512, 2)
+    valid = torch.cat([b5["video_mask"], b5["attention_mask"]], 1).bool()
+    assert (lg5 - g14["logits"])[valid].abs().max().item() < 5e-2
+    score = lg5[:, cfg.max_feats:][b5["input_ids"] == MASK].softmax(-1)[:, 0]
+    assert (score - g14["score"]).abs().max().item() < 1e-2
+
+
+def test_lazy_logits_every_accessor_and_autograd():
+    """With labels the forward computes the labelled rows only; the [B,S,V] logits are filled on first access through ANY
+    accessor of the output mapping, equal to an eager run, and stay wired into autograd (loss + a loss on the logits)."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=77, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = to_dev(synth_batch(cfg, B=3, L=33, seed=9))
+    nolab = {k: v for k, v in batch.items() if k != "labels"}
+    with torch.no_grad():
+        want = m(**nolab).logits.clone()  # eager path (no labels)
+    for access in (lambda o: o.logits, lambda o: o["logits"], lambda o: o[1], lambda o: o.get("logits"),
+                   lambda o: dict(o)["logits"], lambda o: list(o.values())[1], lambda o: dict(o.items())["logits"],
+                   lambda o: {**o}["logits"]):
+        with torch.no_grad():
+            out = m(**batch)
+            assert out.__dict__.get("_fill") is not None  # nothing filled yet
+            got = access(out)
+        assert torch.equal(got, want)
+    # differentiable: d(loss + f(logits)) == d loss + d f(logits) (two separate runs)
+    def grads(use_loss, use_logits):
+        for p in m.parameters():
+            p.grad = None
+        out = m(**batch)
+        tot = 0
+        if use_loss:
+            tot = tot + out.loss
+        if use_logits:
+            tot = tot + out.logits[:, :, :7].float().pow(2).mean()
+        tot.backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+
+    ga, gb, gab = grads(True, False), grads(False, True), grads(True, True)
+    for n in ga:  # (three separate runs: bf16 rounding noise of the backward operands differs between them)
+        assert _rel_fro(gab[n], ga[n] + gb[n]) < 2e-2, (n, _rel_fro(gab[n], ga[n] + gb[n]))
+    assert max(v.abs().max().item() for v in gb.values()) > 0
+
+
+def test_fused_adam_resumes_reference_checkpoint(golden):
+    """A checkpoint the reference wrote (G16: torch.optim.Adam state, main.py:290-300) restores the HIP model and the fused
+    optimizer; evaluate and one resumed epoch through the product's loops track what the reference did with the same file."""
+    import json
+    import os
+
+    from frozenbilm_amd import main as P_main
+    from frozenbilm_amd.optim import FusedAdam
+    from frozenbilm_amd.util.checkpoint import load_checkpoint, save_checkpoint
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_videotext_batches
+    from tests.test_inputs_checkpoint import DELTA_KEYS, REF_CKPT
+
+    meta = golden("G16_checkpoint_meta", raw=True)
+    cfg = _tiny_cfg(max_feats=4, vocab_size=300, max_position_embeddings=128)
+    m = build(cfg, O.synth_params(cfg, seed=23, std=0.08))
+    m.adapter_dropout = 0.0
+    m.config.hidden_dropout_prob = m.config.attention_probs_dropout_prob = 0.0  # G16 was taken with dropout 0
+    opt = FusedAdam(m, lr=5e-4, betas=(0.9, 0.95))
+    ck, start = load_checkpoint(m, REF_CKPT, opt, resume=True)
+    assert start == 1 and opt._step == 3 and opt.param_groups[0]["lr"] == 1e-3
+    eng = m.engine()
+    n0 = "deberta.encoder.layer.1.output.adapter.up.weight"
+    i0 = [n for n, p in m.named_parameters() if p.requires_grad].index(n0)
+    o, k = eng.offsets[n0], eng.named[n0].numel()
+    assert torch.equal(opt._m[o:o + k].cpu().view_as(ck["optimizer"]["state"][i0]["exp_avg"]), ck["optimizer"]["state"][i0]["exp_avg"])
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videotext_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, 3, 6, seed=32)
+    torch.manual_seed(10)
+    ev = P_main.evaluate(m, tok, ListLoader(batches), torch.device(DEV), args)
+    ref = json.loads(str(meta["eval_stats"]))
+    assert abs(ev["loss"] - ref["loss"]) < 2e-2, (ev, ref)
+    before = {k_: m.get_param(k_).detach().clone() for k_ in DELTA_KEYS}
+    torch.manual_seed(11)
+    tr = P_main.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device(DEV), 1, args, 0.1)
+    ref = json.loads(str(meta["resume_train_stats"]))
+    assert abs(tr["loss"] - ref["loss"]) < 2e-2, (tr, ref)
+    for k_ in DELTA_KEYS:
+        d = (m.get_param(k_).detach() - before[k_]).flatten().float().cpu()
+        r = torch.as_tensor(meta[f"resume_delta/{k_}"]).flatten()
+        cos = (torch.dot(d, r) / (d.norm() * r.norm() + 1e-30)).item()
+        assert cos > 0.9, (k_, cos)  # Adam's sign-like update amplifies bf16 gradient noise on near-zero entries
+    # and a file written HERE carries torch.optim.Adam's schema (the reference can resume it)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "c.pth")
+        save_checkpoint(m, opt, 1, args, path)
+        ck2 = torch.load(path, map_location="cpu", weights_only=False)
+        assert set(ck2["optimizer"]) == {"state", "param_groups"} and len(ck2["optimizer"]["state"]) == 46
+        named = [p for p in m.parameters() if p.requires_grad]
+        topt = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in named], lr=1.0)
+        topt.load_state_dict(ck2["optimizer"])  # torch accepts it as its own
+        assert topt.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+        m2 = build(cfg, O.synth_params(cfg, seed=24, std=0.08))
+        opt2 = FusedAdam(m2, lr=1.0)
+        load_checkpoint(m2, path, opt2, resume=True)
+        assert opt2._step == opt._step and torch.equal(opt2._m, opt._m) and torch.equal(opt2._v, opt._v)
+        assert m2.step_seed == m.step_seed
+
+
+def test_grad_reducer_on_the_hip_engine_nccl():
+    """GradReducer attached to the HIP model with an RCCL (nccl) process group over the visible devices (world 1 on the
+    test box: the collectives run, degenerate): gradients identical to the run without a reducer; the launched spans are
+    ordered, contiguous and cover the flat buffer, cut at the engine's real bucket keys; the reducer survives an engine
+    rebuild (load_state_dict / set_answer_embeddings after attach -- the reference's call order); accumulate() holds the
+    exchange over several backward passes (mc.py)."""
+    import socket
+
+    import torch.distributed as dist
+
+    from frozenbilm_amd.parallel import GradReducer
+
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=81, std=0.05, ln_jitter=0.1)
+    batch = to_dev(synth_batch(cfg, B=4, L=50, seed=3))
+    m0 = build(cfg, P)
+    m0(**batch).loss.backward()
+    want = {n: p.grad.clone() for n, p in m0.named_parameters() if p.requires_grad}
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+        created = True
+    try:
+        m = build(cfg, P)
+        red = GradReducer.attach(m, min_bucket_elems=1)
+        eng0 = m.engine()
+        m.load_state_dict(P, strict=False)  # invalidates the engine AFTER the reducer was attached
+        m.to(DEV)
+        eng = m.engine()
+        assert eng is not eng0 and eng.reducer is red and red.flat_grad.data_ptr() == eng.flat_grad.data_ptr()
+        red.world = 2  # force the collective + 1/world path on the single rank: all-reduce over 1 rank is the identity
+        m(**batch).loss.backward()
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert torch.allclose(p.grad, want[n] * 0.5, rtol=1e-6, atol=0), n  # SUM over 1 rank, then / world(=2)
+        spans = red.last_launched
+        assert spans[0][0] == 0 and spans[-1][1] == eng.flat_grad.numel()
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        ends = set(eng.bucket_ends.values())
+        assert all(e in ends for _, e in spans), "buckets must be cut at the engine's backward stages"
+        assert len(spans) >= cfg.num_hidden_layers + 2
+        # several backward passes feed one exchange
+        red.world = 1
+        for p in m.parameters():
+            p.grad = None
+        with red.accumulate():
+            m(**batch).loss.backward()
+            assert not red.launched and not red.pending
+            m(**batch).loss.backward()
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert torch.allclose(p.grad, 2 * want[n], rtol=1e-3, atol=1e-7), n
+        assert red.last_launched == [(0, eng.flat_grad.numel())]
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -59,7 +59,7 @@ def test_checkpoint_reference_schema_roundtrip(tmp_path):
     path = os.path.join(tmp_path, "checkpoint0000.pth")
     save_checkpoint(m, opt, 0, args, path)
     ck = torch.load(path, map_location="cpu", weights_only=False)
-    assert set(ck) == {"model", "optimizer", "epoch", "args"}
+    assert set(ck) == {"model", "optimizer", "epoch", "args", "fbl"}  # "fbl": dropout-stream position (extra key)
     # state_dict keys are the reference's, including its position_ids buffer
     assert set(ck["model"]) == set(O.param_shapes(cfg)) | {"deberta.embeddings.position_ids"}
     m2 = _model(cfg, None)
@@ -89,3 +89,61 @@ def test_checkpoint_reference_schema_roundtrip(tmp_path):
     torch.save({"model": sub, "optimizer": None, "epoch": 0, "args": args}, path2)
     with pytest.raises(RuntimeError):
         load_checkpoint(m3, path2)
+
+
+REF_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G16_reference_checkpoint.pth")
+DELTA_KEYS = ("deberta.embeddings.linear_video.weight", "deberta.encoder.layer.1.output.adapter.up.weight",
+              "deberta.encoder.layer.0.attention.output.adapter.down.weight", "deberta.encoder.LayerNorm.weight")
+
+
+def test_reference_written_checkpoint_loads_and_resumes(golden):
+    """SURVEY 8(f) rank 4 against a file the REFERENCE wrote (golden G16: main.py's epoch + its own save_on_master call,
+    main.py:290-300 / util/dist.py:195-198): the product's load_checkpoint restores model and optimizer, and the product's
+    loops continue exactly where the reference's continue (evaluate, then one resumed epoch)."""
+    import json
+
+    from frozenbilm_amd import main as P_main
+    from frozenbilm_amd.util.checkpoint import load_checkpoint
+    from oracle.model_wrapper import OracleModel
+    from tests.downstream_fixtures import Args, ListLoader, StubTokenizer, make_videotext_batches
+
+    meta = golden("G16_checkpoint_meta", raw=True)
+    order = [str(n) for n in meta["trainable_order"]]
+    cfg = _tiny_cfg(max_feats=4, vocab_size=300, max_position_embeddings=128)
+    m = _model(cfg, O.synth_params(cfg, seed=23, std=0.08))  # different weights: everything must come from the file
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == order, "optimizer-state index space differs"
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.95))
+    ck, start = load_checkpoint(m, REF_CKPT, opt, resume=True)
+    assert start == 1 and set(ck) == {"model", "optimizer", "epoch", "args"}
+    sd = m.state_dict()
+    for k, v in ck["model"].items():
+        if "lm_head.decoder" in k:
+            continue  # the reference's untied copy of the word embeddings (not a parameter of the path)
+        assert torch.equal(sd[k], v), k
+    assert opt.param_groups[0]["lr"] == 1e-3
+    for i, p in enumerate(opt.param_groups[0]["params"]):
+        assert torch.equal(opt.state[p]["exp_avg"], ck["optimizer"]["state"][i]["exp_avg"]), order[i]
+    # continue on the CPU oracle model with the loaded weights, driven by the PRODUCT's loops
+    P = {k: v.clone() for k, v in sd.items() if "position_ids" not in k}
+    om = OracleModel(cfg, P)
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videotext_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, 3, 6, seed=32)
+    torch.manual_seed(10)
+    ev = P_main.evaluate(om, tok, ListLoader(batches), torch.device("cpu"), args)
+    ref = json.loads(str(meta["eval_stats"]))
+    for k in ref:
+        assert abs(ev[k] - ref[k]) < 2e-5, (k, ev[k], ref[k])
+    named = om.named_ref_parameters()
+    opt2 = torch.optim.Adam([named[n] for n in order], lr=5e-4, betas=(0.9, 0.95))
+    opt2.load_state_dict(ck["optimizer"])
+    before = {k: named[k].detach().clone() for k in DELTA_KEYS}
+    torch.manual_seed(11)
+    tr = P_main.train_one_epoch(om, tok, ListLoader(batches), opt2, torch.device("cpu"), 1, args, 0.1)
+    ref = json.loads(str(meta["resume_train_stats"]))
+    for k in ref:
+        assert abs(tr[k] - ref[k]) < 2e-5, (k, tr[k], ref[k])
+    for k in DELTA_KEYS:
+        d = (om.named_ref_parameters()[k].detach() - before[k]).flatten()
+        r = torch.as_tensor(meta[f"resume_delta/{k}"]).flatten()
+        assert torch.dot(d, r) / (d.norm() * r.norm() + 1e-30) > 0.999, k
+        assert (d - r).norm() / r.norm() < 2e-3, k

@@ -198,3 +198,21 @@ def test_g8_bert_base_config1(golden):
     assert abs(out["loss"].item() - g["loss"].item()) < 1e-5
     assert torch.equal(lg.argmax(-1), g["argmax"])  # token indices bit-exact
     assert torch.equal(lg.topk(5, -1).indices[:, ::5], g["top5"])
+
+
+def test_bf16_operand_mode_is_opt_in_and_close():
+    """oracle.bf16_operands (the HIP path's arithmetic contract for tight gradient checks) changes nothing unless
+    entered, and inside it the outputs move by bf16 rounding only."""
+    from tests.golden.make_goldens import _tiny_cfg, synth_batch
+
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    batch = synth_batch(cfg, B=3, L=27, seed=55)
+    with torch.no_grad():
+        a = O.forward(P, cfg, **batch)
+        with O.bf16_operands():
+            b = O.forward(P, cfg, **batch)
+        c = O.forward(P, cfg, **batch)
+    assert torch.equal(a["logits"], c["logits"])
+    err = (a["logits"] - b["logits"]).abs().max().item()
+    assert 0 < err < 5e-2, err
