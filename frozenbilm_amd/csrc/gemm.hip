@@ -373,6 +373,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.kskip_len = kskip_len;
   g.kskip_steps = kskip_steps;
   g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
+  g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
   if (p_drop > 0.f) {
     if (act != FBL_ACT_RELU || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
     g.drop_thresh = fbl_drop_thresh(p_drop);
@@ -383,7 +384,27 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
   const bool big = !force_small && !accumulate && batch == 1 && p_drop <= 0.f && M >= 2048 && N >= 1024 &&
                    ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
-  if (big && splitk_ws_floats >= 0) {  // (negative values mark the two halves of an already split launch)
+  // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
+  // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
+  // the CUs the last round does not need start up to 0.4 tiles late, which costs no wall time and takes the CUs out of
+  // lockstep (measured [9024,4608,1536]: 146 -> 133 us).  With a nearly empty last round (FFN-up: 816 tiles, 48 left) the
+  // split stays better: an epilogue costs a CU 10-20 us of VALU / store time that nothing on that CU overlaps, so a
+  // fourth round of full tiles (222 us) loses to three rounds plus small tiles (208 us).  FBL_GEMM8_SKEW=0 disables.
+  static const int skew_mode = getenv("FBL_GEMM8_SKEW") ? atoi(getenv("FBL_GEMM8_SKEW")) : 50;
+  static const int gemm8_on = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
+  bool skewed_single_launch = false;
+  if (big && splitk_ws_floats >= 0 && skew_mode > 0 && gemm8_on > 0 && gemm8_eligible(g)) {
+    const long total = (long)((N + 255) / 256) * ((M + 255) / 256);
+    const long rem = total % 256;
+    if (total > 256 && rem >= 96 && rem <= 192) {
+      skewed_single_launch = true;
+      g.skew_first = (int)rem;
+      g.skew_blocks = 256;
+      const double tile_us = (K / 64) * 1.4 + 10.0;  // measured: 1.4 us per K-tile + epilogue
+      g.skew_ticks = (int)(tile_us * 100.0 / 5.0 * 0.01 * skew_mode);  // four groups, (1..4) x skew_mode/5 % of a tile late
+    }
+  }
+  if (big && splitk_ws_floats >= 0 && !skewed_single_launch) {  // (negative values mark the two halves of an already split launch)
     // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
     // round would be mostly empty, give the big tiles only as many M rows as fill whole rounds and run the remaining
     // rows with the 128x128 configuration (2 workgroups/CU, 1/4 of the work per tile) right behind.
@@ -444,16 +465,21 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.tiles_m = use_224 ? (M + 223) / 224 : use_64 ? (M + 63) / 64 : (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
   dim3 grid(g.tiles_m * g.tiles_n, batch * splitk);
-  // The 8-phase kernel (gemm8.hip) takes every launch of the 256-row configurations it is instantiated for, including
-  // the shapes the 2-stage kernel ran with 224x256 tiles (measured: [8512,1536,6144] 915 -> 1139 TFLOP/s although only
-  // 204 of 256 CUs get a tile).  FBL_GEMM8=0 switches it off, FBL_GEMM8=1 keeps the 224x256 shapes on the old kernel.
-  static const int gemm8_mode = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 2;
+  // The 8-phase kernel (gemm8.hip) takes every launch of the 256- / 224-row configurations it is instantiated for.
+  // FBL_GEMM8=0 switches it off, 1 keeps the 224x256 shapes on the 2-stage kernel, 2 runs them as 256x256 8-phase tiles
+  // (measured: [8512,1536,6144] 915 -> 1139 TFLOP/s although only 204 of 256 CUs get a tile), 3 (default) as 224x256
+  // 8-phase tiles (228 tiles).
+  static const int gemm8_mode = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
   if (use_big && gemm8_mode > 0 && (!use_224 || gemm8_mode >= 2) && gemm8_eligible(g)) {
     GemmArgs g8 = g;
-    g8.tiles_m = (M + 255) / 256;
-    g8.tiles_n = (N + 255) / 256;
-    const int rc8 = launch_gemm8(g8, act, aux_kind, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
-    if (rc8 != FBL_ERR_ARG) return rc8;
+    const bool r224 = use_224 && gemm8_mode >= 3;
+    for (int attempt = r224 ? 0 : 1; attempt < 2; ++attempt) {  // 224-row tiles first where they apply, then 256-row tiles
+      const int bm = attempt == 0 ? 224 : 256;
+      g8.tiles_m = (M + bm - 1) / bm;
+      g8.tiles_n = (N + 255) / 256;
+      const int rc8 = launch_gemm8(g8, act, aux_kind, attempt == 0, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
+      if (rc8 != FBL_ERR_ARG) return rc8;
+    }
   }
 #define FBL_GEMM_LAUNCH_NW(NW_, ACT_, AUX_, SK_, MI_)                                                           \
   do {                                                                                                         \

@@ -55,7 +55,9 @@ constexpr int RING_BYTES = 8 * HT_BYTES;     // 128 KiB
 constexpr int SMEM8_BYTES = (8 * 64 * 68 * 4 > RING_BYTES) ? 8 * 64 * 68 * 4 : RING_BYTES;  // epilogue staging is larger
 
 // VAR bit 0: stagger the two wave rows by half a phase; bit 1: s_setprio around the MFMA cluster (experiment switches)
-template <int ACT, int AUX, int VAR>
+// R224: 224-row tile (halves of 112 rows: the first wave row owns 64 rows of each half, the second one 48 = three 16-row
+// MFMA tiles) for the M = 8512, N = 1536 GEMMs of the step: 38 x 6 = 228 tiles instead of 204 that are 14 % bigger.
+template <int ACT, int AUX, int VAR, bool R224 = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -64,8 +66,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
   tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  if (g.skew_ticks > 0 && (int)blockIdx.x >= g.skew_first && (int)blockIdx.x < g.skew_blocks) {
+    // first-round workgroups [skew_first, skew_blocks): four groups, 1..4 skew steps late
+    const int k = 1 + (((int)blockIdx.x - g.skew_first) * 4) / (g.skew_blocks - g.skew_first);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t wait = (uint64_t)k * (uint64_t)g.skew_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  constexpr int HROWS = R224 ? 112 : 128;  // rows of an A half-tile
+  const int m0 = tm * (2 * HROWS), n0 = tn * 256;
   const int nk = g.K / BK;  // even, >= 4
+  const bool short_rows = R224 && wm == 1;  // this wave owns 3 (not 4) row tiles per half
 
   // ---- LDS-DMA source offsets (bytes from A / B, K-tile 0).  One instruction of the workgroup covers 64 rows of a
   // half-tile (wave w: rows 8w..8w+7 of them, lane -> row lane>>3, physical chunk lane&7), two instructions a half-tile.
@@ -76,9 +87,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = h * 128 + (j * 8 + wave) * 8 + lrow;
-      const int am = min(m0 + r, g.M - 1);
-      const int bn = min(n0 + r, g.N - 1);
+      const int rr = (j * 8 + wave) * 8 + lrow;  // row inside the half-tile slot
+      // (224-row tiles: slot rows 112..127 are never read; their lanes re-request row 111 so that every wave issues
+      //  the same number of DMA instructions and one vmcnt count serves all)
+      const int am = min(m0 + h * HROWS + min(rr, HROWS - 1), g.M - 1);
+      const int bn = min(n0 + h * 128 + rr, g.N - 1);
       a_off[h][j] = (uint32_t)(((long)am * g.lda + lchunk * 8) * 2);
       b_off[h][j] = (uint32_t)(((long)bn * g.ldb + lchunk * 8) * 2);
     }
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   auto read_a = [&](auto Hc, auto Bc) {
     constexpr int SLOT = (decltype(Bc)::value * 4 + (decltype(Hc)::value ? 3 : 0)) * HT_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {  // (the fourth row tile of a short wave reads slot rows it never uses: harmless)
       af[i][0] = *(const bf16x8*)(smem + SLOT + i * 2048 + a_rd0);
       af[i][1] = *(const bf16x8*)(smem + SLOT + i * 2048 + a_rd1);
     }
@@ -134,12 +147,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
       }
     }
   };
-  auto mma = [&](auto RHc, auto CHc) {
-    constexpr int RH = decltype(RHc)::value, CH = decltype(CHc)::value;
+  auto mma_n = [&](auto RHc, auto CHc, auto NRc) {
+    constexpr int RH = decltype(RHc)::value, CH = decltype(CHc)::value, NR = decltype(NRc)::value;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (CH == 0)
@@ -148,10 +161,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             acc[2 + j][RH * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j][s], af[i][s], acc[2 + j][RH * 4 + i], 0, 0, 0);
         }
   };
-
   // One phase of K-tile kt (ring buffer BUF).  TAIL < 0: steady state (issue the half-tile six ahead, keep four in
   // flight); TAIL = k >= 0: nothing left to issue, k half-tiles may stay in flight.
-  auto phase = [&](auto Qc, auto Bc, auto Tc, int kt) {
+  auto phase = [&](auto Qc, auto Bc, auto Tc, int kt, auto NRc) {
     constexpr int Q = decltype(Qc)::value, BUF = decltype(Bc)::value, TAIL = decltype(Tc)::value;
     if constexpr (Q == 0) {
       read_b(IC<0>{}, Bc);
@@ -179,10 +191,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
-    if constexpr (Q == 0) mma(IC<0>{}, IC<0>{});
-    else if constexpr (Q == 1) mma(IC<0>{}, IC<1>{});
-    else if constexpr (Q == 2) mma(IC<1>{}, IC<1>{});
-    else mma(IC<1>{}, IC<0>{});
+    if constexpr (Q == 0) mma_n(IC<0>{}, IC<0>{}, NRc);
+    else if constexpr (Q == 1) mma_n(IC<0>{}, IC<1>{}, NRc);
+    else if constexpr (Q == 2) mma_n(IC<1>{}, IC<1>{}, NRc);
+    else mma_n(IC<1>{}, IC<0>{}, NRc);
     if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -201,26 +213,37 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     if (wm == 1) __builtin_amdgcn_s_barrier();
   }
 
-  for (int kt = 0; kt + 2 < nk; kt += 2) {  // K-tile pairs with a full pipeline behind them
-    phase(IC<0>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<1>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<2>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<3>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<0>{}, IC<1>{}, IC<-1>{}, kt + 1);
-    phase(IC<1>{}, IC<1>{}, IC<-1>{}, kt + 1);
-    phase(IC<2>{}, IC<1>{}, IC<-1>{}, kt + 1);
-    phase(IC<3>{}, IC<1>{}, IC<-1>{}, kt + 1);
-  }
-  {  // last pair: the pipeline drains (sequence numbers stop at 4*nk - 1)
-    const int kt = nk - 2;
-    phase(IC<0>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<1>{}, IC<0>{}, IC<-1>{}, kt);
-    phase(IC<2>{}, IC<0>{}, IC<3>{}, kt);
-    phase(IC<3>{}, IC<0>{}, IC<2>{}, kt);
-    phase(IC<0>{}, IC<1>{}, IC<1>{}, kt + 1);
-    phase(IC<1>{}, IC<1>{}, IC<0>{}, kt + 1);
-    phase(IC<2>{}, IC<1>{}, IC<0>{}, kt + 1);
-    phase(IC<3>{}, IC<1>{}, IC<0>{}, kt + 1);
+  // The whole K loop as one function of the number of row tiles this wave multiplies (4; 3 for the second wave row of a
+  // 224-row tile): two complete copies of the loop instead of a branch around every MFMA group -- the barriers pair up
+  // across the copies, and each copy gets its own register allocation.
+  auto k_loop = [&](auto NRc) {
+    for (int kt = 0; kt + 2 < nk; kt += 2) {  // K-tile pairs with a full pipeline behind them
+      phase(IC<0>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<1>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<2>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<3>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<0>{}, IC<1>{}, IC<-1>{}, kt + 1, NRc);
+      phase(IC<1>{}, IC<1>{}, IC<-1>{}, kt + 1, NRc);
+      phase(IC<2>{}, IC<1>{}, IC<-1>{}, kt + 1, NRc);
+      phase(IC<3>{}, IC<1>{}, IC<-1>{}, kt + 1, NRc);
+    }
+    {  // last pair: the pipeline drains (sequence numbers stop at 4*nk - 1)
+      const int kt = nk - 2;
+      phase(IC<0>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<1>{}, IC<0>{}, IC<-1>{}, kt, NRc);
+      phase(IC<2>{}, IC<0>{}, IC<3>{}, kt, NRc);
+      phase(IC<3>{}, IC<0>{}, IC<2>{}, kt, NRc);
+      phase(IC<0>{}, IC<1>{}, IC<1>{}, kt + 1, NRc);
+      phase(IC<1>{}, IC<1>{}, IC<0>{}, kt + 1, NRc);
+      phase(IC<2>{}, IC<1>{}, IC<0>{}, kt + 1, NRc);
+      phase(IC<3>{}, IC<1>{}, IC<0>{}, kt + 1, NRc);
+    }
+  };
+  if constexpr (R224) {
+    if (short_rows) k_loop(IC<3>{});
+    else k_loop(IC<4>{});
+  } else {
+    k_loop(IC<4>{});
   }
   if constexpr (VAR & 1) {
     if (wm == 0) __builtin_amdgcn_s_barrier();  // balances the extra barrier of the second wave row
@@ -235,17 +258,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     return;
   }
   const int ec = (lane & 15) * 4;
-  gemm_epilogue<ACT, AUX, false, 8>(g, smem, wave, lane, acc, m0 + wm * 64, 128, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
-                                    0, 0);
+  gemm_epilogue<ACT, AUX, false, 8>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
+                                    0, 0, short_rows ? 48 : 64);
 }
 
-template <int ACT, int AUX>
+template <int ACT, int AUX, bool R224>
 int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   static const int var = getenv("FBL_GEMM8_VAR") ? atoi(getenv("FBL_GEMM8_VAR")) : 3;
 #define FBL_G8_LAUNCH(VAR_)                                                                                     \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
-    auto kfn = gemm8_kernel<ACT, AUX, VAR_>;                                                                    \
+    auto kfn = gemm8_kernel<ACT, AUX, VAR_, R224>;                                                              \
     if (!attr_set) {                                                                                            \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES); \
       if (e != hipSuccess) return (int)e;                                                                       \
@@ -253,7 +276,7 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     }                                                                                                           \
     hipLaunchKernelGGL(kfn, grid, dim3(512), SMEM8_BYTES, stream, g);                                           \
   } while (0)
-  if constexpr (ACT == FBL_ACT_NONE && AUX == FBL_AUX_NONE) {  // the experiment variants exist for the plain epilogue only
+  if constexpr (ACT == FBL_ACT_NONE && AUX == FBL_AUX_NONE && !R224) {  // the experiment variants exist for the plain epilogue only
     if (var == 0) FBL_G8_LAUNCH(0);
     else if (var == 1) FBL_G8_LAUNCH(1);
     else if (var == 2) FBL_G8_LAUNCH(2);
@@ -277,14 +300,19 @@ bool gemm8_eligible(const GemmArgs& g) {
   return true;
 }
 
-int launch_gemm8(const GemmArgs& g, int act, int aux_kind, dim3 grid, hipStream_t stream) {
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE>(g, grid, stream);
-  if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU, FBL_AUX_NONE>(g, grid, stream);
-  if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU_GRAD, FBL_AUX_NONE>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_BF16>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_BF16>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16>(g, grid, stream);
+int launch_gemm8(const GemmArgs& g, int act, int aux_kind, bool rows224, dim3 grid, hipStream_t stream) {
+  if (rows224) {  // the N = 1536 GEMMs of the step: plain (one or two outputs) and residual-add epilogues
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, true>(g, grid, stream);
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, true>(g, grid, stream);
+    return FBL_ERR_ARG;
+  }
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, false>(g, grid, stream);
+  if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU, FBL_AUX_NONE, false>(g, grid, stream);
+  if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU_GRAD, FBL_AUX_NONE, false>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, false>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_BF16, false>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_BF16, false>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16, false>(g, grid, stream);
   return FBL_ERR_ARG;
 }
 

@@ -40,6 +40,12 @@ struct GemmArgs {
   uint32_t drop_thresh;
   float drop_inv_keep;
   long drop_ld;
+  // 8-phase kernel only: start skew.  One workgroup fits a CU, so the first skew_blocks (= CU count) workgroups start
+  // together and every CU then runs its sequence of tiles in lockstep with all others -- main loops (MFMA) all at once,
+  // epilogues (HBM traffic) all at once.  The workgroups [skew_first, skew_blocks) of the first round -- as many as there
+  // are CUs the partial LAST round does not need, so the delay costs no wall time -- wait 1..4 x skew_ticks ticks of the
+  // 100 MHz real-time clock before they start: their CUs' epilogues then overlap the other CUs' main loops.
+  int skew_first, skew_blocks, skew_ticks;
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -71,9 +77,12 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
 //   acc[ni][mi]: 16x16 tile ni (of 4) along n, mi (of MI) along m.  The wave's rows leave in slabs of 64: slab `half`
 //   starts at global row m_first + half*m_slab_stride; this lane's 4 staged columns (lane&15)*4.. map to the global
 //   columns n4..n4+3.
+//   slab_rows (<= 64): rows of a slab that belong to this wave (the 224-row configuration of the 8-phase kernel gives
+//   its second wave row 48 of them); rows beyond it are not stored.
 template <int ACT, int AUX, bool SPLITK, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
-                                              int m_first, int m_slab_stride, int n4, int batch, int ks) {
+                                              int m_first, int m_slab_stride, int n4, int batch, int ks,
+                                              int slab_rows = 64) {
   constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
   float* stage = (float*)smem + wave * (64 * LDW);
   const int frow = lane & 15, fg = lane >> 4;
@@ -148,7 +157,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       if (it >= cnt * 4) break;
       const int row = it * 4 + er;
       const int m = mslab + row;
-      if (m >= g.M) continue;
+      if (m >= g.M || row >= slab_rows) continue;
       const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
       const float rs = rsv[it];
       float v[4], pre[4];
@@ -224,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
 
 // 8-phase 256x256 kernel (gemm8.hip).  Returns 0 when launched, FBL_ERR_ARG for an epilogue combination it does not
 // instantiate (the caller then uses the 2-stage kernel).
-int launch_gemm8(const GemmArgs& g, int act, int aux_kind, dim3 grid, hipStream_t stream);
+int launch_gemm8(const GemmArgs& g, int act, int aux_kind, bool rows224, dim3 grid, hipStream_t stream);
 bool gemm8_eligible(const GemmArgs& g);
 
 }  // namespace fblgemm
