@@ -36,12 +36,16 @@ template <int NW> struct TileCfg {
 template <int NW, int ACT, int AUX, bool SPLITK, int SCHED = 0, int MI_ = NW, bool KSKIP = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
   using Cfg = TileCfg<NW>;
-  constexpr int BN = Cfg::BN, TILE_BYTES = Cfg::TILE_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES;
   constexpr int MI = MI_;           // 16-row MFMA tiles per wave along M; 4 tiles (64 cols) along N
   constexpr int BM = 32 * MI;
+  // LDS stage = A image | B image.  The 2-stage loops reserve the square tile's A image even for shorter tiles; the
+  // ring of SCHED 5 packs the BM rows it really has (three stages of 24 KiB: two workgroups per CU still fit)
+  constexpr int BN = Cfg::BN;
+  constexpr int TILE_BYTES = (SCHED == 5) ? BM * BK * 2 : Cfg::TILE_BYTES;
+  constexpr int STAGE_BYTES = (SCHED == 5) ? TILE_BYTES + Cfg::TILE_BYTES : Cfg::STAGE_BYTES;
   constexpr int WC = NW / 2;        // waves along N (2 rows of waves along M)
   constexpr int WROWS = MI * 16;    // rows of C per wave
-  static_assert(SCHED == 0 || MI_ == NW, "the counted-vmcnt schedules assume the square tile");
+  static_assert(SCHED == 0 || SCHED == 5 || MI_ == NW, "the counted-vmcnt schedules assume the square tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -135,6 +139,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
       if (kt + 2 < kt1) issue(kt + 2, stage);
       if constexpr (SCHED == 4) mfma_block(af0, bf0);
       mfma_block(af1, bf1);
+    }
+    __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
+  } else if constexpr (SCHED == 5) {
+    // ---- ring of NS = 3 stages for the tall, narrow problems (adapter bottleneck projections: about one 64x128 workgroup
+    // per CU, so nothing else on the CU hides a load): two K-steps of operands in flight, ONE raw barrier per K-step.
+    //   iteration kt:  wait until stage kt has landed (one younger stage may stay in flight) -> barrier (every wave's part
+    //   of stage kt is in LDS AND every wave is done reading stage kt-1) -> request stage kt+2 into the slot of kt-1 ->
+    //   fragments + MFMAs of stage kt.
+    constexpr int NS = 3;
+    constexpr int PS = 4 + ((BM + NW * 8 - 1) / (NW * 8) < 4 ? (BM + NW * 8 - 1) / (NW * 8) : 4);  // LDS-DMA requests per thread and stage
+    static_assert(PS == 6, "the vmcnt immediates below are written for the 64-row configuration (2 A + 4 B requests)");
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (kt0 + s_ < kt1) issue(kt0 + s_, s_);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < kt1) issue(kt + NS - 1, (kt - kt0 + NS - 1) % NS);
+      const char* base = smem + ((kt - kt0) % NS) * STAGE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[MI], bfg[4];
+        read_frags(base, s, af, bfg);
+        mfma_block(af, bfg);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of the stage are complete
     }
     __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
   } else if constexpr (KSKIP) {
@@ -493,10 +525,25 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, dim3(NW_ * 64), smem_bytes, (hipStream_t)stream, g);                         \
   } while (0)
+  static const int deep64 = getenv("FBL_GEMM_DEEP") ? atoi(getenv("FBL_GEMM_DEEP")) : 1;
+#define FBL_GEMM_LAUNCH_DEEP(ACT_, AUX_)                                                                        \
+  do {                                                                                                         \
+    static bool attr_set = false;                                                                              \
+    auto kfn = gemm_bf16_nt_kernel<4, ACT_, AUX_, false, 5, 2>;                                                \
+    constexpr int smem_bytes = 3 * (64 * BK * 2 + TileCfg<4>::TILE_BYTES);                                     \
+    static_assert(smem_bytes >= 4 * 64 * 68 * 4, "ring must cover the epilogue staging");                      \
+    if (!attr_set) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes); \
+      if (e != hipSuccess) return (int)e;                                                                      \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), smem_bytes, (hipStream_t)stream, g);                              \
+  } while (0)
 #define FBL_GEMM_LAUNCH(ACT_, AUX_, SK_)                              \
   do {                                                                \
     if (use_224) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 7);         \
     else if (use_big) FBL_GEMM_LAUNCH_NW(8, ACT_, AUX_, false, 8);    \
+    else if (use_64 && deep64) FBL_GEMM_LAUNCH_DEEP(ACT_, AUX_);      \
     else if (use_64) FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, false, 2);     \
     else FBL_GEMM_LAUNCH_NW(4, ACT_, AUX_, SK_, 4);                   \
   } while (0)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_mat_kernel(LnMatArgs a) {
 // ---- LayerNorm backward: persistent grid of LNB_BLOCKS blocks x 4 waves; each wave strides over rows and keeps its
 // dgamma/dbeta partial in registers; block-reduced through LDS into ws[block][2][H]; a second tiny kernel folds ws
 // into dgamma/dbeta (+=), deterministic.
-constexpr int LNB_BLOCKS = 256;
+constexpr int LNB_BLOCKS = 1024;  // four 4-wave blocks per CU
 struct LnBwdArgs {
   const float* dout; const int32_t* rowmask; const float* t; const float* stats; const float* gamma;
   float p_drop; uint64_t seed; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
@@ -174,7 +174,7 @@ template <int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   constexpr int VEC = (EPL % 4 == 0) ? 4 : ((EPL % 2 == 0) ? 2 : 1);
   constexpr int NIT = EPL / VEC;
-  __shared__ float red[4 * 3 * 64 * EPL];  // [wave][3][H]: dgamma, dbeta, colsum(dy)
+  __shared__ float red[4 * 64 * EPL];  // [wave][H]: cross-wave fold of one column sum at a time (dgamma, dbeta, colsum(dy))
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H;
   float dg[EPL], db[EPL], dys[EPL], gam[EPL];
@@ -226,24 +226,121 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       if (a.out_dy_f32) stf<VEC>(a.out_dy_f32 + (long)row * H + col, dy);
     }
   }
+  // the three column sums leave one after the other through the same [4][H] LDS tile (a third of the LDS of folding them
+  // together: 24.6 KiB per block at H = 1536, so several blocks share a CU)
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int col = (it * 64 + lane) * VEC;
+  for (int which = 0; which < 3; ++which) {
+    const float* src = which == 0 ? dg : (which == 1 ? db : dys);
+    if (which) __syncthreads();
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-      red[(wave * 3 + 0) * H + col + c] = dg[it * VEC + c];
-      red[(wave * 3 + 1) * H + col + c] = db[it * VEC + c];
-      red[(wave * 3 + 2) * H + col + c] = dys[it * VEC + c];
+    for (int it = 0; it < NIT; ++it) {
+      const int col = (it * 64 + lane) * VEC;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) red[wave * H + col + c] = src[it * VEC + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 256) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s_ += red[w * H + i];
+      a.ws[(long)blockIdx.x * 3 * H + which * H + i] = s_;
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 3 * H; i += 256) {
-    float s = 0.f;
+}
+// Two waves per row (column halves), two rows per block iteration: half the per-lane state of ln_bwd_kernel (which needs
+// > 256 registers at H = 1536 and therefore runs one wave per SIMD), so four waves per SIMD keep enough rows in flight to
+// cover the HBM latency.  The two halves of a row exchange their (sum g, sum g*xhat) partials through LDS: one barrier
+// per iteration, double-buffered.  Same arithmetic and the same deterministic ws / fold protocol as ln_bwd_kernel.
+template <int EPL>
+__global__ __launch_bounds__(256, 3) void ln_bwd2_kernel(LnBwdArgs a) {
+  static_assert(EPL % 2 == 0, "two waves share a row");
+  constexpr int EW = EPL / 2;  // elements per lane
+  constexpr int VEC = (EW % 4 == 0) ? 4 : ((EW % 2 == 0) ? 2 : 1);
+  constexpr int NIT = EW / VEC;
+  __shared__ float red[2 * 64 * EPL];  // [row slot][H]
+  __shared__ float xch[2][2][2][2];    // [parity][slot][half][s1, s2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = wave >> 1, half = wave & 1;
+  const int H = a.H;
+  const int c0 = half * (H / 2);
+  float dg[EW], db[EW], dys[EW], gam[EW];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[w * 3 * H + i];
-    a.ws[(long)blockIdx.x * 3 * H + i] = s;
+  for (int e = 0; e < EW; ++e) dg[e] = db[e] = dys[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) ldf<VEC>(a.gamma + c0 + (it * 64 + lane) * VEC, gam + it * VEC);
+  const uint32_t thr = fbl_drop_thresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  int par = 0;
+  for (int base = blockIdx.x * 2; base < a.N; base += gridDim.x * 2, par ^= 1) {
+    const int row = base + slot;
+    const bool live = row < a.N;
+    const int rr = live ? row : a.N - 1;
+    const float mean = a.stats[2 * (long)rr], rstd = a.stats[2 * (long)rr + 1];
+    const float om = live ? (a.rowmask ? (float)a.rowmask[rr] : 1.0f) : 0.f;
+    float g[EW], xh[EW];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int col = c0 + (it * 64 + lane) * VEC;
+      float d[VEC], x[VEC];
+      ldf<VEC>(a.dout + (long)rr * H + col, d);
+      ldf<VEC>(a.t + (long)rr * H + col, x);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const int e = it * VEC + c;
+        const float dd = d[c] * om;
+        xh[e] = (x[c] - mean) * rstd;
+        dg[e] += dd * xh[e];
+        db[e] += dd;
+        g[e] = dd * gam[e];
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      xch[par][slot][half][0] = s1;
+      xch[par][slot][half][1] = s2;
+    }
+    __syncthreads();
+    // (both halves add the two partials in the same order: bit-identical s1 / s2 on both waves of a row)
+    s1 = (xch[par][slot][0][0] + xch[par][slot][1][0]) / (float)H;
+    s2 = (xch[par][slot][0][1] + xch[par][slot][1][1]) / (float)H;
+    if (live) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int col = c0 + (it * 64 + lane) * VEC;
+        float dt[VEC], dy[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          const int e = it * VEC + c;
+          dt[c] = rstd * (g[e] - s1 - xh[e] * s2);
+          dy[c] = dt[c];
+          if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+          dys[e] += dy[c];
+        }
+        if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
+        if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * H + col, dy);
+        if (a.out_dy_f32) stf<VEC>(a.out_dy_f32 + (long)row * H + col, dy);
+      }
+    }
+  }
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    const float* src = which == 0 ? dg : (which == 1 ? db : dys);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int col = c0 + (it * 64 + lane) * VEC;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) red[slot * H + col + c] = src[it * VEC + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 256) a.ws[(long)blockIdx.x * 3 * H + which * H + i] = red[i] + red[H + i];
   }
 }
+
 // fold [nblk][ncols] partial sums: a block owns 16 columns, its 16 row-groups stride over the partial rows
 __device__ __forceinline__ float fold16(const float* ws, int nblk, int ncols, int col) {
   __shared__ float red[16][17];
@@ -699,10 +796,27 @@ extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float
   if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
   if (N <= 0) return 0;
   LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H};
-  int nblk = (N + 3) / 4;
-  if (nblk > LNB_BLOCKS) nblk = LNB_BLOCKS;
-  dim3 grid(nblk);
-  FBL_EPL_DISPATCH(H, ln_bwd_kernel, grid, a, (hipStream_t)stream);
+  int nblk;
+  if ((H / 64) % 2 == 0) {  // two waves per row, two rows per block iteration
+    nblk = (N + 1) / 2;
+    if (nblk > LNB_BLOCKS) nblk = LNB_BLOCKS;
+    dim3 grid(nblk);
+    switch (H / 64) {
+      case 2: hipLaunchKernelGGL(ln_bwd2_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL(ln_bwd2_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 8: hipLaunchKernelGGL(ln_bwd2_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 12: hipLaunchKernelGGL(ln_bwd2_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 16: hipLaunchKernelGGL(ln_bwd2_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 24: hipLaunchKernelGGL(ln_bwd2_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      case 32: hipLaunchKernelGGL(ln_bwd2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+      default: return FBL_ERR_SHAPE;
+    }
+  } else {
+    nblk = (N + 3) / 4;
+    if (nblk > LNB_BLOCKS) nblk = LNB_BLOCKS;
+    dim3 grid(nblk);
+    FBL_EPL_DISPATCH(H, ln_bwd_kernel, grid, a, (hipStream_t)stream);
+  }
   FBL_CHECK_LAUNCH();
   if (dgamma || dbeta || dysum) {
     hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
