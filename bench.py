@@ -83,7 +83,12 @@ def main():
     ap.add_argument("--eval-forward", action="store_true", help="time the eval forward only (reported under its own metric)")
     ap.add_argument("--full-logits", action="store_true", help="read .logits in every timed step (reference-eager head)")
     ap.add_argument("--no-extras", action="store_true", help="skip the with_full_logits / eval_forward / host side measurements")
+    ap.add_argument("--workload", default="mlm", choices=["mlm", "videoqa", "mc"],
+                    help="mlm = BASELINE configs[1] (the headline); videoqa = configs[3] (zero-shot open-ended eval loop, "
+                         "n_ans=1000); mc = configs[4] (4-way multiple choice, B=8, S=512)")
     args = ap.parse_args()
+    if args.workload != "mlm":
+        return run_downstream(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -249,6 +254,91 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_downstream(args):
+    """BASELINE configs[3] / configs[4] on one GPU: the product's videoqa.evaluate / mc.evaluate loops (reference
+    signatures) over synthetic batches resident in HBM; a step = one batch through the loop body (forward, [MASK]-row
+    head, softmax, top-k / candidate arg-max).  Own metric names: these lines are not the headline."""
+    import types
+
+    from frozenbilm_amd import mc as P_mc
+    from frozenbilm_amd import videoqa as P_vqa
+    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = DebertaV2Config(num_hidden_layers=args.layers)
+    torch.manual_seed(0)
+    vqa = args.workload == "videoqa"
+    n_ans = 1000 if vqa else 2
+    model = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1, n_ans=n_ans)
+    model.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    a2tok = torch.randint(5, cfg.vocab_size, (n_ans, 5), generator=g)
+    a2tok = a2tok * (torch.arange(5)[None] < torch.randint(1, 6, (n_ans, 1), generator=g))
+    model.set_answer_embeddings(a2tok.to(dev))
+    MASK, B, T, F = 128000, (32 if vqa else 8), 10, 1024
+    Lt = 256 if vqa else 502
+    C = 1 if vqa else 4
+
+    class Tok:  # the loops only need the ids; texts are pre-tokenised id lists
+        mask_token_id, pad_token_id, sep_token_id = MASK, 0, 2
+
+        def __call__(self, text, **kw):
+            ids = torch.stack(text)
+            return {"input_ids": ids, "attention_mask": (ids != 0).long()}
+
+    def texts(seed):
+        gg = torch.Generator().manual_seed(seed)
+        tlen = torch.randint(Lt // 8, Lt + 1, (B,), generator=gg)
+        tlen[-1] = Lt
+        ids = torch.randint(5, 127000, (B, Lt), generator=gg) * (torch.arange(Lt)[None] < tlen[:, None])
+        ids[torch.arange(B), torch.stack([torch.randint(1, int(t), (1,), generator=gg) for t in tlen]).view(-1)] = MASK
+        return list(ids)
+
+    video = torch.randn(B, T, F, generator=g).half().float()
+    vlen = torch.randint(1, T + 1, (B,), generator=g)
+    batch = dict(video=video.to(dev), video_len=vlen, qid=list(range(B)), type=[0] * B,
+                 answer_id=torch.randint(0, n_ans if vqa else C, (B,), generator=g),
+                 text=texts(11) if vqa else [texts(11 + c) for c in range(C)])
+    largs = types.SimpleNamespace(max_feats=T, use_video=True, suffix="", use_context=True, max_tokens=Lt, print_freq=10 ** 9)
+
+    class Loader(list):
+        dataset = list(range(B))
+
+    tok = Tok()
+
+    def step():
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            if vqa:
+                return P_vqa.evaluate(model, tok, Loader([batch]), dev, "msrvtt", largs, thresholds=[1, 10])
+            return P_mc.evaluate(model, tok, Loader([batch]), dev, "how2qa", largs)
+
+    for _ in range(args.warmup + 3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    S = T + Lt
+    fwd_f, _ = algorithmic_flops_per_sample(S=S, V=n_ans)
+    tf = fwd_f * B * C * args.steps / dt / 1e12
+    out = {"metric": ("zero-shot open-ended VideoQA eval samples/sec (videoqa.evaluate, n_ans=1000)" if vqa else
+                      "multiple-choice VideoQA eval questions/sec (mc.evaluate, 4 candidates, S=512)"),
+           "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[{3 if vqa else 4}]: DeBERTa-v2-XLarge({args.layers}L)+adapters, B={B}, T=10x1024, L={Lt} "
+                                  f"(S={S}), n_ans={n_ans}, {C} candidate(s) per question in ONE forward of {B * C} samples, eval loop "
+                                  "incl. host-side result bookkeeping, head on the [MASK] rows only"},
+           "candidate_forwards_per_s": B * C * args.steps / dt, "algorithmic_tflops": tf, "frac_of_peak": tf / PEAK_BF16_TFLOPS}
+    print(json.dumps(out))
 
 
 def spawn_ranks(n: int) -> int:

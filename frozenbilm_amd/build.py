@@ -43,10 +43,26 @@ def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    # A kernel that touches scratch (private) memory -- spilled registers, or a register array the compiler could not
+    # keep in registers because a loop around it was not unrolled -- is several times slower than intended: refuse it.
+    bad, name = [], "?"
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[")[0].strip()
+        elif "ScratchSize [bytes/lane]:" in line:
+            n = int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
+            if n > 64:  # (a handful of spilled registers outside the inner loop is tolerated and only reported)
+                bad.append(f"{name}: {n} bytes/lane")
+            elif n > 0:
+                print(f"[frozenbilm_amd.build] note: {name} spills {n} bytes/lane")
+    if bad and os.environ.get("FBL_ALLOW_SCRATCH", "0") != "1":
+        os.remove(obj)
+        raise RuntimeError(f"{os.path.basename(src)}: kernels using scratch memory (set FBL_ALLOW_SCRATCH=1 to build anyway):\n  "
+                           + "\n  ".join(bad))
     return obj
 
 

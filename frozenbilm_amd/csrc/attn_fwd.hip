@@ -13,6 +13,8 @@
 // query column, so softmax statistics are in-lane + 2 shuffles, and P feeds the P.V MFMA straight from registers
 // (the k-slot order of that MFMA is permuted identically on the V^T operand).  The next key tile's global loads are
 // issued into registers before the current tile is computed (HBM/L2 latency hides under the MFMA + LDS work).
+#include <stdlib.h>
+
 #include "attn_common.h"
 #include "../../include/fbl.h"
 
@@ -32,6 +34,7 @@ struct AttnArgs {
   long ldo;
   float* lse;
   int B, S, Sp, nh, span2;
+  int dbg;  // ablation switches (FBL_ATTN_DBG; 0 in production)
 };
 
 constexpr int SM_KS = 0;                        // [64][64] bf16 swizzled
@@ -153,9 +156,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       sacc[nt] = acc;
     }
     // ---- (2) T1 for this wave's queries, (3) T2 for key tile w
+    if (!(a.dbg & 2)) {
     bias_tile(smem + SM_PK, off1, qf[0], qf[1], T1w + c * LT, c, g);
     bias_tile(smem + SM_PQ, off2w, lds_frag(smem + SM_KS, w * 16 + c, g), lds_frag(smem + SM_KS, w * 16 + c, 4 + g),
               T2 + (w * 16 + c) * LT, c, g, kms[w * 16 + c] != 0.f);  // masked keys: whole T2 row = -inf
+    }
     __syncthreads();
 
     // ---- (4) gather the bias terms, online softmax.  No clamps: in-range (i, j) always land inside the 80-wide
@@ -172,8 +177,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const f16* t2n = t2g - base2[nt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int wi = ib[63 - nt * 16 - r];
-          const float s = sacc[nt][r] + (float)t1row[wi] + (float)t2n[(nt * 16 + r) * LT + wi];
+          float s = sacc[nt][r];
+          if (!(a.dbg & 1)) {
+            const int wi = ib[63 - nt * 16 - r];
+            s += (float)t1row[wi] + (float)t2n[(nt * 16 + r) * LT + wi];
+          }
           p[nt * 4 + r] = s;
           mx = fmaxf(mx, s);
         }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     m_run = m_new;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-    if (a.p_drop > 0.f) {
+    if (a.p_drop > 0.f && !(a.dbg & 8)) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     // ---- (5) O^T += V^T . P^T ; k-slot e of step kk  <->  key kk*32 + (e>>2)*16 + g*4 + (e&3)
+    if (!(a.dbg & 4))
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 pf;
@@ -261,7 +270,9 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldp % 8) || (ldo % 4)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, 0};
+  static const int dbg = getenv("FBL_ATTN_DBG") ? atoi(getenv("FBL_ATTN_DBG")) : 0;
+  a.dbg = dbg;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL);

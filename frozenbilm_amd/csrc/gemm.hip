@@ -374,7 +374,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                         int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                         int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
-                        float p_drop, uint64_t drop_seed, void* stream) {
+                        float p_drop, uint64_t drop_seed, void* stream, int seg_n = 0, void* seg_out = nullptr,
+                        int64_t seg_ld = 0, int64_t drop_row0 = 0) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
@@ -406,15 +407,20 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.kskip_steps = kskip_steps;
   g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
   g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
+  g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
+  if (seg_n > 0) {
+    if ((seg_n & 3) || seg_n >= N || !seg_out || accumulate || batch != 1) return FBL_ERR_ARG;
+    g.drop_ld = seg_ld;
+  }
   if (p_drop > 0.f) {
-    if (act != FBL_ACT_RELU || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
+    if ((act != FBL_ACT_RELU && seg_n <= 0) || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
     g.drop_thresh = fbl_drop_thresh(p_drop);
     g.drop_inv_keep = 1.f / (1.f - p_drop);
   }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
-  const bool big = !force_small && !accumulate && batch == 1 && p_drop <= 0.f && M >= 2048 && N >= 1024 &&
+  const bool big = !force_small && !accumulate && batch == 1 && (p_drop <= 0.f || seg_n > 0) && M >= 2048 && N >= 1024 &&
                    ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
   // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
   // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
@@ -456,7 +462,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
         int rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
                               out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
-                              p_drop, drop_seed, stream);
+                              p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0);
         if (rc) return rc;
         const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
         return gemm_nt_impl((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
@@ -465,7 +471,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                                 out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
                                 out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
                                 out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
-                                1, nullptr, -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, stream);
+                                1, nullptr, -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, stream, seg_n,
+                                seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big);
       }
     }
   }
@@ -620,6 +627,21 @@ extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void*
                                     void* stream) {
   return gemm_nt_impl(x_bf16, ldx, wd_bf16, ldw, M, A, K, bias, nullptr, 1.0f, FBL_ACT_RELU, FBL_AUX_NONE, nullptr, 0,
                       nullptr, z_bf16, nullptr, ldz, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream);
+}
+
+// One GEMM for a dense layer AND the down-projection of the adapter that follows it (model/deberta.py:255-257, 329-331:
+// dense -> adapter; model/adapter.py:38-41): with Wm = [W ; Wd.W] ([N1 + A, K]; the lower A rows are the down-projection
+// composed with the dense weight, rebuilt by the caller whenever Wd changes) and bm = [b ; Wd.b + bd],
+//     [ y | z_pre ] = x . Wm^T + bm,     C = y (fp32 and/or bf16, N1 columns),     z = dropout_p(relu(z_pre)) (bf16, A columns).
+// The bottleneck activations come out of the epilogue of the tile column(s) beyond N1 -- no separate K = N1 GEMM that
+// re-reads y, no launch.  Dropout keys as in fbl_adapter_down_fwd: (seed, m*ldz + a).  N1 % 4 == 0.
+extern "C" int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1,
+                                          int A, int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy,
+                                          float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream) {
+  if (A <= 0 || (N1 & 3)) return FBL_ERR_ARG;
+  return gemm_nt_impl(x_bf16, ldx, wm_bf16, ldw, M, N1 + A, K, bias_m, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_NONE, nullptr, 0,
+                      y_f32, y_bf16, nullptr, ldy, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, N1,
+                      z_bf16, ldz);
 }
 
 extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

@@ -295,7 +295,7 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 bool gemm8_eligible(const GemmArgs& g) {
   const int nk = g.K / BK;
   if (g.K % BK || nk < 4 || (nk & 1)) return false;
-  if (g.a_kblk || g.kskip_len || g.splitk != 1 || g.drop_thresh) return false;
+  if (g.a_kblk || g.kskip_len || g.splitk != 1 || (g.drop_thresh && g.seg_n <= 0)) return false;
   if ((long)g.M * g.lda * 2 >= (1l << 32) || (long)g.N * g.ldb * 2 >= (1l << 32)) return false;
   return true;
 }

@@ -40,12 +40,19 @@ struct GemmArgs {
   uint32_t drop_thresh;
   float drop_inv_keep;
   long drop_ld;
+  long drop_row0;  // row offset added to m in the dropout key (the rows of a split launch keep their global keys)
   // 8-phase kernel only: start skew.  One workgroup fits a CU, so the first skew_blocks (= CU count) workgroups start
   // together and every CU then runs its sequence of tiles in lockstep with all others -- main loops (MFMA) all at once,
   // epilogues (HBM traffic) all at once.  The workgroups [skew_first, skew_blocks) of the first round -- as many as there
   // are CUs the partial LAST round does not need, so the delay costs no wall time -- wait 1..4 x skew_ticks ticks of the
   // 100 MHz real-time clock before they start: their CUs' epilogues then overlap the other CUs' main loops.
   int skew_first, skew_blocks, skew_ticks;
+  // Second output segment (fbl_dense_adapter_down_fwd): columns n >= seg_n are NOT part of C but the adapter bottleneck
+  // z[m, n - seg_n] = dropout(relu(v)) (bf16, row stride seg_ld; dropout = drop_* keyed by m*seg_ld + n - seg_n), whatever
+  // ACT / AUX the kernel was instantiated with.  seg_n == 0: off.  seg_n % 4 == 0.
+  int seg_n;
+  bf16* seg_out;
+  long seg_ld;
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -77,12 +84,73 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
 //   acc[ni][mi]: 16x16 tile ni (of 4) along n, mi (of MI) along m.  The wave's rows leave in slabs of 64: slab `half`
 //   starts at global row m_first + half*m_slab_stride; this lane's 4 staged columns (lane&15)*4.. map to the global
 //   columns n4..n4+3.
+// Epilogue of the tile columns that belong to the second output segment of a merged dense + adapter-down GEMM
+// (GemmArgs::seg_n): z[m, n - seg_n] = dropout(relu(alpha*acc + bias[n])), bf16.  Kept out of gemm_epilogue's row loop on
+// purpose: that loop is fully unrolled, and a larger body makes the compiler give up unrolling the slab loop around it
+// (the accumulator array then lives in scratch memory).
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_seg(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
+                                               int m_first, int m_slab_stride, int n4, int slab_rows) {
+  constexpr int LDW = 68;
+  float* stage = (float*)smem + wave * (64 * LDW);
+  const int frow = lane & 15, fg = lane >> 4;
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? g.bias[n4 + r] : 0.f;
+  }
+  const int nz = n4 - g.seg_n;
+  const bool vec = (n4 + 3 < g.N) && ((g.seg_ld & 3) == 0);
+#pragma unroll
+  for (int half = 0; half < (MI + 3) / 4; ++half) {
+    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;
+    const int mslab = m_first + half * m_slab_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      if (half * 4 + mi < MI) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+      }
+    if (n4 < g.N) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        if (it >= cnt * 4) break;
+        const int row = it * 4 + er;
+        const int m = mslab + row;
+        if (m >= g.M || row >= slab_rows) continue;
+        const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaxf(a4[r] * g.alpha + bv[r], 0.f);
+          if (g.drop_thresh)
+            v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.seg_ld + (uint64_t)(nz + r), g.drop_thresh, g.drop_inv_keep);
+        }
+        bf16* zp = g.seg_out + (long)m * g.seg_ld + nz;
+        if (vec) {
+          *(bf16x4*)zp = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n4 + r < g.N) zp[r] = f2bf(v[r]);
+        }
+      }
+    }
+  }
+}
+
 //   slab_rows (<= 64): rows of a slab that belong to this wave (the 224-row configuration of the 8-phase kernel gives
 //   its second wave row 48 of them); rows beyond it are not stored.
 template <int ACT, int AUX, bool SPLITK, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
                                               int m_first, int m_slab_stride, int n4, int batch, int ks,
                                               int slab_rows = 64) {
+  if (!SPLITK && g.seg_n > 0 && n4 >= g.seg_n) {  // (uniform per workgroup: seg_n is a multiple of the tile width)
+    gemm_epilogue_seg<MI>(g, smem, wave, lane, acc, m_first, m_slab_stride, n4, slab_rows);
+    return;
+  }
   constexpr int LDW = 68;  // floats per staged row (64 + 4: conflict-free b128 writes)
   float* stage = (float*)smem + wave * (64 * LDW);
   const int frow = lane & 15, fg = lane >> 4;
@@ -182,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       if (ACT == FBL_ACT_RELU && g.drop_thresh) {  // dropout(relu(.)) of the adapter bottleneck, same keys as fbl_dropout_bf16
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)m * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
+          v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
       }
       if (AUX != FBL_AUX_NONE) {
         const long ao = er_x + (long)(it * 4) * g.ld_aux;

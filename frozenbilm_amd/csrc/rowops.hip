@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_mat_kernel(LnMatArgs a) {
 // ---- LayerNorm backward: persistent grid of LNB_BLOCKS blocks x 4 waves; each wave strides over rows and keeps its
 // dgamma/dbeta partial in registers; block-reduced through LDS into ws[block][2][H]; a second tiny kernel folds ws
 // into dgamma/dbeta (+=), deterministic.
-constexpr int LNB_BLOCKS = 1024;  // four 4-wave blocks per CU
+constexpr int LNB_BLOCKS = 768;  // three 4-wave blocks per CU (the kernels run 3 waves per SIMD)
 struct LnBwdArgs {
   const float* dout; const int32_t* rowmask; const float* t; const float* stats; const float* gamma;
   float p_drop; uint64_t seed; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
@@ -356,14 +356,37 @@ __device__ __forceinline__ float fold16(const float* ws, int nblk, int ncols, in
   }
   return s;
 }
+// A block owns 64 consecutive columns of ws[nblk][3H]: 16 lanes x float4 read 256 contiguous bytes of a partial row, the
+// 16 lane groups stride over the rows (full cache lines: the 16-column variant above reads 64-byte pieces), then a
+// fixed-order fold of the 16 groups through LDS -- deterministic.
 __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta,
                                                           float* dysum) {
-  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
-  const float s = fold16(ws, nblk, 3 * H, i);
-  if ((threadIdx.x >> 4) == 0 && i < 3 * H) {
-    if (i < H) { if (dgamma) dgamma[i] += s; }
-    else if (i < 2 * H) { if (dbeta) dbeta[i - H] += s; }
-    else if (dysum) dysum[i - 2 * H] += s;
+  __shared__ f32x4 red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + tx * 4;
+  const int ncols = 3 * H;  // (H % 64 == 0: a block never straddles two of the three sums, nor the end)
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (col < ncols) {
+    const float* p = ws + col;
+    int b = ty;
+    for (; b + 48 < nblk; b += 64) {  // four independent loads in flight
+      const f32x4 a0 = *(const f32x4*)(p + (long)b * ncols), a1 = *(const f32x4*)(p + (long)(b + 16) * ncols);
+      const f32x4 a2 = *(const f32x4*)(p + (long)(b + 32) * ncols), a3 = *(const f32x4*)(p + (long)(b + 48) * ncols);
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < nblk; b += 16) s += *(const f32x4*)(p + (long)b * ncols);
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < ncols) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][tx];
+    float* dst = col < H ? dgamma : (col < 2 * H ? dbeta : dysum);
+    if (dst) {
+      float* q = dst + (col % H);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += s[r];
+    }
   }
 }
 
@@ -819,7 +842,7 @@ extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float
   }
   FBL_CHECK_LAUNCH();
   if (dgamma || dbeta || dysum) {
-    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
                        dgamma, dbeta, dysum);
     FBL_CHECK_LAUNCH();
   }

@@ -153,22 +153,52 @@ class Engine:
 
     def _pack_frozen(self):
         P, H, I = self.P, self.H, self.I
+        nL, dev = self.nL, self.dev
         bf = lambda t: t.to(BF16).contiguous()
+        # A dense layer followed by an adapter runs as ONE GEMM against [W ; Wd.W] (fbl_dense_adapter_down_fwd): the
+        # composed rows Wd.W change with every optimizer step and are rebuilt by two batched GEMMs per site type
+        # (refresh_trainable_operands).  For those, the transposed frozen weights of all layers live in one tensor, in
+        # REVERSE layer order (index j = nL-1-layer) -- the order of the adapters in the flat trainable buffer.
+        self.merge1 = bool(self.A1) and self.A1 % 8 == 0 and H % 4 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
+        self.merge2 = bool(self.A2) and self.A2 % 8 == 0 and H % 4 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
+        self.WoT_rev = torch.empty(nL, H, H, dtype=BF16, device=dev)
+        self.WdT_rev = torch.empty(nL, I, H, dtype=BF16, device=dev)
+        if self.merge1:
+            self.WoM_rev = torch.zeros(nL, H + self.A1, H, dtype=BF16, device=dev)
+            self.boM_rev = torch.zeros(nL, H + self.A1, dtype=F32, device=dev)
+            self.bo16_rev = torch.zeros(nL, 1, H, dtype=BF16, device=dev)
+        if self.merge2:
+            self.WdM_rev = torch.zeros(nL, H + self.A2, I, dtype=BF16, device=dev)
+            self.bdM_rev = torch.zeros(nL, H + self.A2, dtype=F32, device=dev)
+            self.bd16_rev = torch.zeros(nL, 1, H, dtype=BF16, device=dev)
         self.Lw = []
         for i in range(self.nL):
             p = f"deberta.encoder.layer.{i}"
             s = p + ".attention.self."
+            j = nL - 1 - i
             Wqkv = torch.cat([P[s + "query_proj.weight"], P[s + "key_proj.weight"], P[s + "value_proj.weight"]], 0)
+            self.WoT_rev[j].copy_(P[p + ".attention.output.dense.weight"].t())
+            self.WdT_rev[j].copy_(P[p + ".output.dense.weight"].t())
             d = dict(
                 Wqkv=bf(Wqkv), WqkvT=bf(Wqkv.t()),
                 bqkv=torch.cat([P[s + "query_proj.bias"], P[s + "key_proj.bias"], P[s + "value_proj.bias"]]).float().contiguous(),
-                Wo=bf(P[p + ".attention.output.dense.weight"]), WoT=bf(P[p + ".attention.output.dense.weight"].t()),
+                Wo=bf(P[p + ".attention.output.dense.weight"]), WoT=self.WoT_rev[j],
                 bo=P[p + ".attention.output.dense.bias"].float().contiguous(),
                 Wi=bf(P[p + ".intermediate.dense.weight"]), WiT=bf(P[p + ".intermediate.dense.weight"].t()),
                 bi=P[p + ".intermediate.dense.bias"].float().contiguous(),
-                Wd=bf(P[p + ".output.dense.weight"]), WdT=bf(P[p + ".output.dense.weight"].t()),
+                Wd=bf(P[p + ".output.dense.weight"]), WdT=self.WdT_rev[j],
                 bd=P[p + ".output.dense.bias"].float().contiguous(),
             )
+            if self.merge1:
+                self.WoM_rev[j, :H].copy_(d["Wo"])
+                self.boM_rev[j, :H].copy_(d["bo"])
+                self.bo16_rev[j, 0].copy_(d["bo"])
+                d["WoM"], d["boM"] = self.WoM_rev[j], self.boM_rev[j]
+            if self.merge2:
+                self.WdM_rev[j, :H].copy_(d["Wd"])
+                self.bdM_rev[j, :H].copy_(d["bd"])
+                self.bd16_rev[j, 0].copy_(d["bd"])
+                d["WdM"], d["bdM"] = self.WdM_rev[j], self.bdM_rev[j]
             self.Lw.append(d)
         if self.cfg.conv_kernel_size:
             w = P["deberta.encoder.conv.conv.weight"]  # [H_out, H_in, 3] -> [H_out, k*H_in + c]
@@ -219,6 +249,16 @@ class Engine:
                 ent[key] = dict(down=down, up=up, A=A, Ap=Ap, name=p + blk,
                                 bd=self.P[p + blk + ".down.bias"], bu=self.P[p + blk + ".up.bias"])
             self.ad.append(ent)
+        # composed rows of the merged dense + down-projection weights: off the critical path, on the side stream (layer 0
+        # first -- the forward reaches its merged GEMM after ~0.3 ms -- then all other layers in one strided batch)
+        if self.merge1 or self.merge2:
+            if self.use_side_stream:
+                self.side.wait_stream(torch.cuda.current_stream())  # the bf16 cast of the flat buffer above
+                with torch.cuda.stream(self.side):
+                    self._compose_ev = self._compose_adapter_down(events=True)
+            else:
+                self._compose_adapter_down()
+                self._compose_ev = None
         if self.F:
             wv = self.Pb["deberta.embeddings.linear_video.weight"]
             if self.Fp != self.F:
@@ -226,6 +266,53 @@ class Engine:
                 w2[:, : self.F] = wv
                 wv = w2
             self.Wv = wv
+
+    def _compose_adapter_down(self, events=False):
+        """Rows [H, H+A) of the merged weights / biases: Wd.W and Wd.b + bd for every layer (see _pack_frozen), from the
+        current adapter weights.  Layers nL-1 .. 1 sit at a constant stride in the flat trainable buffer: one strided-batch
+        GEMM each for the matrix and the bias; layer 0 (the conv LayerNorm sits between it and layer 1) gets its own and
+        goes first.  events=True: returns (event after layer 0, event after everything) recorded on the current stream."""
+        H, nL = self.H, self.nL
+        sites = []
+        for on, blk, A, WT, WM, bM, b16 in ((self.merge1, ".attention.output.adapter", self.A1, self.WoT_rev,
+                                             getattr(self, "WoM_rev", None), getattr(self, "boM_rev", None),
+                                             getattr(self, "bo16_rev", None)),
+                                            (self.merge2, ".output.adapter", self.A2, self.WdT_rev,
+                                             getattr(self, "WdM_rev", None), getattr(self, "bdM_rev", None),
+                                             getattr(self, "bd16_rev", None))):
+            if not on:
+                continue
+            ow = [self.offsets[f"deberta.encoder.layer.{i}{blk}.down.weight"] for i in range(nL)]
+            ob = [self.offsets[f"deberta.encoder.layer.{i}{blk}.down.bias"] for i in range(nL)]
+            if nL >= 3 and len({ow[i - 1] - ow[i] for i in range(2, nL)}) == 1 and \
+                    len({ob[i - 1] - ob[i] for i in range(2, nL)}) == 1 and ow[nL - 2] - ow[nL - 1] == ob[nL - 2] - ob[nL - 1] > 0:
+                groups = [(nL - 1, 1, ow[0], ob[0], A * H), (0, nL - 1, ow[nL - 1], ob[nL - 1], ow[nL - 2] - ow[nL - 1])]
+            else:
+                groups = [(nL - 1 - i, 1, ow[i], ob[i], A * H) for i in range(nL)]
+            sites.append((A, WT, WM, bM, b16, groups))
+
+        def run_group(A, WT, WM, bM, b16, grp):
+            j0, nb, o_w, o_b, st = grp
+            wd3 = torch.as_strided(self.flat_bf16, (nb, A, H), (st, H, 1), o_w)
+            L.gemm(wd3, WT[j0:j0 + nb], out_bf16=WM[j0:j0 + nb, H:H + A, :])                # Wd . W
+            bd3 = torch.as_strided(self.flat, (nb, A, 1), (st, 1, 1), o_b)
+            bo3 = torch.as_strided(bM, (nb, A, 1), (bM.stride(0), 1, 1), bM[j0, H:].storage_offset())
+            L.gemm(wd3, b16[j0:j0 + nb], aux=bd3, aux_kind=L.AUX_ADD_F32, out_f32=bo3)      # Wd . b + bd
+
+        for A, WT, WM, bM, b16, groups in sites:  # layer 0 of every site first
+            run_group(A, WT, WM, bM, b16, groups[0])
+        ev0 = ev1 = None
+        if events:
+            ev0 = torch.cuda.Event()
+            ev0.record()
+        for A, WT, WM, bM, b16, groups in sites:
+            for grp in groups[1:]:
+                run_group(A, WT, WM, bM, b16, grp)
+        if events:
+            ev1 = torch.cuda.Event()
+            ev1.record()
+            return ev0, ev1
+        return None
 
     def _adapter_bwd_operands(self, ent):
         """W^T operands for the adapter backward (trainable, so rebuilt after every optimizer step): all adapters of a
@@ -263,7 +350,7 @@ class Engine:
         return ent["upT"], ent["downT"]
 
     # ------------------------------------------------------------------ public entry
-    def run(self, input_ids, attention_mask, video, video_mask, labels, mlm, want_hidden):
+    def run(self, input_ids, attention_mask, video, video_mask, labels, mlm, want_hidden, logit_rows=None):
         m = self.m
         train = m.training
         need_grad = torch.is_grad_enabled() and any(self.named[n].requires_grad for n in self.order)
@@ -307,8 +394,17 @@ class Engine:
         run.rows = rows_labelled if full_labels is not None else None
         self.refresh_trainable_operands()
         use_ans = bool(m.n_ans) and not mlm
+        if logit_rows is not None:
+            if need_grad or full_labels is not None:
+                raise RuntimeError("logit_rows is an inference-time option (no labels, no gradient bookkeeping)")
+            run.logit_rows = logit_rows.to(self.dev).to(torch.int32).contiguous().view(-1)
         logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden)
         Vout = self.n_ans if use_ans else self.V
+        if logit_rows is not None:
+            res = {"logits": logits[:, :Vout], "loss": None, "run": run}
+            if want_hidden:
+                res["hidden_states"] = run.hidden_out
+            return res
         res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None, "run": run}
         if want_hidden:
             res["hidden_states"] = run.hidden_out
@@ -341,15 +437,40 @@ class Engine:
                  out_f32=of, N=N, H=H)
         return Stream(bf16=ob, norm=NormRef(t, stats, g, b, rowmask), plain=of, full=full if tail else None), seed
 
-    def _adapter_fwd(self, run, ent, x_f32, x_bf16, N):
-        """y = x + up(drop(relu(down(x))))  (model/adapter.py:33-45) as two epilogue-fused GEMMs."""
+    def _adapter_fwd(self, run, ent, x_f32, x_bf16, N, z=None, seed=0):
+        """y = x + up(drop(relu(down(x))))  (model/adapter.py:33-45).  The bottleneck z either comes from the merged
+        dense + down-projection GEMM of the caller (z given) or from fbl_adapter_down_fwd; the up-projection is a GEMM
+        with bias + residual epilogue."""
         A, Ap = ent["A"], ent["Ap"]
-        z = torch.zeros(N, Ap, dtype=BF16, device=self.dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=self.dev)
-        seed = run.next_seed() if run.p_ad > 0 else 0
-        L.adapter_down_fwd(x_bf16, ent["down"], ent["bd"], z, A=A, p_drop=run.p_ad, seed=seed)  # ReLU + dropout in the epilogue
+        if z is None:
+            z = torch.zeros(N, Ap, dtype=BF16, device=self.dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=self.dev)
+            seed = run.next_seed() if run.p_ad > 0 else 0
+            L.adapter_down_fwd(x_bf16, ent["down"], ent["bd"], z, A=A, p_drop=run.p_ad, seed=seed)  # ReLU + dropout in the epilogue
         y = torch.empty(N, self.H, dtype=F32, device=self.dev)
         L.gemm(z, ent["up"], bias=ent["bu"], aux=x_f32, aux_kind=L.AUX_ADD_F32, out_f32=y)
         return y, z, seed
+
+    def _dense_adapter(self, run, li, x_bf16, W, wkey, bkey, ent, A, merged, N):
+        """dense -> adapter (model/deberta.py:255-257 / :329-331): returns (y fp32 = adapter output, dense output bf16, z,
+        dropout seed).  Merged form: one GEMM gives the dense output and the adapter bottleneck."""
+        H, dev = self.H, self.dev
+        o32 = torch.empty(N, H, dtype=F32, device=dev)
+        ob = torch.empty(N, H, dtype=BF16, device=dev)
+        if ent is None:
+            L.gemm(x_bf16, W[wkey], bias=W[bkey], out_f32=o32, out_bf16=ob)
+            return o32, ob, None, 0
+        if merged and ent["Ap"] == A:
+            ev = getattr(self, "_compose_ev", None)
+            if ev is not None:  # the composed rows of this layer must be there (layer 0: first event, others: second)
+                torch.cuda.current_stream().wait_event(ev[0] if li == 0 else ev[1])
+            z = torch.empty(N, A, dtype=BF16, device=dev)
+            seed = run.next_seed() if run.p_ad > 0 else 0
+            L.dense_adapter_down_fwd(x_bf16, W[wkey + "M"], W[bkey + "M"], H, z, y_f32=o32, y_bf16=ob, p_drop=run.p_ad, seed=seed)
+            y, z, seed = self._adapter_fwd(run, ent, o32, ob, N, z=z, seed=seed)
+        else:
+            L.gemm(x_bf16, W[wkey], bias=W[bkey], out_f32=o32, out_bf16=ob)
+            y, z, seed = self._adapter_fwd(run, ent, o32, ob, N)
+        return y, ob, z, seed
 
     def _layer_fwd(self, run, li: int, kv: Stream, q: Optional[Stream], Rb: torch.Tensor):
         """One execution of encoder layer ``li`` (model/deberta.py:351-375); q != None is the EMD form where the
@@ -388,13 +509,8 @@ class Engine:
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
                           seed=sv.seed_att, klen=run.klen)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
-        o32 = torch.empty(N, H, dtype=F32, device=dev)
-        ob = torch.empty(N, H, dtype=BF16, device=dev)
-        L.gemm(ctx, W["Wo"], bias=W["bo"], out_f32=o32, out_bf16=ob)
         ad = self.ad[li]
-        y1, z1 = o32, None
-        if "a1" in ad:
-            y1, z1, sv.seed_ad1 = self._adapter_fwd(run, ad["a1"], o32, ob, N)
+        y1, ob, z1, sv.seed_ad1 = self._dense_adapter(run, li, ctx, W, "Wo", "bo", ad.get("a1"), self.A1, self.merge1, N)
         p = f"deberta.encoder.layer.{li}"
         a, sv.seed_ln1 = self._ln(run, p + ".attention.output.LayerNorm", y=y1, resid=(q if q is not None else kv), N=N,
                                   p_drop=run.p_hid)
@@ -403,12 +519,7 @@ class Engine:
         hpre = torch.empty(N, I, dtype=BF16, device=dev) if run.save else None
         # training: the epilogue stores gelu'(pre) (bf16) next to gelu(pre) so the backward epilogue is a plain multiply
         L.gemm(a.bf16, W["Wi"], bias=W["bi"], act=L.ACT_GELU_GRAD if run.save else L.ACT_GELU, out_bf16=h, out_pre=hpre)
-        f32 = torch.empty(N, H, dtype=F32, device=dev)
-        fb = torch.empty(N, H, dtype=BF16, device=dev)
-        L.gemm(h, W["Wd"], bias=W["bd"], out_f32=f32, out_bf16=fb)
-        y2, z2 = f32, None
-        if "a2" in ad:
-            y2, z2, sv.seed_ad2 = self._adapter_fwd(run, ad["a2"], f32, fb, N)
+        y2, fb, z2, sv.seed_ad2 = self._dense_adapter(run, li, h, W, "Wd", "bd", ad.get("a2"), self.A2, self.merge2, N)
         out, sv.seed_ln2 = self._ln(run, p + ".output.LayerNorm", y=y2, resid=Stream(bf16=a.bf16, norm=a.norm), N=N,
                                     p_drop=run.p_hid, tail=self.span2)
         if run.save:
@@ -475,8 +586,15 @@ class Engine:
         if want_hidden:
             run.hidden_out = tuple(self._materialize(s).view(B, S, H) for s in hs)
         # ---- MLM head (:1544-1558): LN(gelu(dense(x))) . table^T + bias
+        hin = q.bf16
+        rows_only = getattr(run, "logit_rows", None)
+        if rows_only is not None:  # inference on selected token rows (the [MASK] rows of videoqa.py:164-168 / mc.py:166-170)
+            N = rows_only.numel()
+            hin = torch.empty(N, H, dtype=BF16, device=dev)
+            if N:
+                L.gather_rows_bf16(q.bf16, rows_only, hin)
         hp = torch.empty(N, H, dtype=F32, device=dev)
-        L.gemm(q.bf16, self.Wh, bias=self.bh, out_f32=hp)
+        L.gemm(hin, self.Wh, bias=self.bh, out_f32=hp)
         hg = torch.empty(N, H, dtype=F32, device=dev)
         L.dropout_gelu_fwd(hp, 0.0, 0, hg)
         hl, _ = self._ln(run, "lm_predictions.lm_head.LayerNorm", y=hg, resid=None, N=N)

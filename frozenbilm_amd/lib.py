@@ -25,6 +25,7 @@ SIGNATURES = {
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
                               _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp]),
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
+    "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -174,6 +175,24 @@ def adapter_down_fwd(x, wd, bias, z, *, A=None, p_drop=0.0, seed=0):
     assert wd.shape[1] == K and z.shape[0] >= M and z.shape[1] >= A
     _chk(load().fbl_adapter_down_fwd(_p(x), ldx, _p(wd), ldw, M, A, K, _p(bias), float(p_drop), int(seed), _p(z), ldz,
                                      _stream()), "fbl_adapter_down_fwd")
+
+
+def dense_adapter_down_fwd(x, wm, bias_m, N1, z, *, y_f32=None, y_bf16=None, p_drop=0.0, seed=0):
+    """[y | z] from one GEMM: y = x @ wm[:N1]^T + bias_m[:N1] (fp32 / bf16), z = dropout(relu(x @ wm[N1:]^T + bias_m[N1:]))."""
+    _req(x, torch.bfloat16, "x"); _req(wm, torch.bfloat16, "wm"); _req(z, torch.bfloat16, "z"); _req(bias_m, torch.float32, "bias")
+    ldx, ldw, ldz = _rows2d(x, "x"), _rows2d(wm, "wm"), _rows2d(z, "z")
+    M, K = x.shape
+    A = wm.shape[0] - N1
+    assert wm.shape[1] == K and A > 0 and z.shape[0] >= M and z.shape[1] >= A and bias_m.numel() >= N1 + A
+    ldy = None
+    for o, dt in ((y_f32, torch.float32), (y_bf16, torch.bfloat16)):
+        if o is not None:
+            _req(o, dt, "y")
+            l = _rows2d(o, "y")
+            assert ldy is None or ldy == l
+            ldy = l
+    _chk(load().fbl_dense_adapter_down_fwd(_p(x), ldx, _p(wm), ldw, M, N1, A, K, _p(bias_m), _p(y_f32), _p(y_bf16), ldy or 0,
+                                           float(p_drop), int(seed), _p(z), ldz, _stream()), "fbl_dense_adapter_down_fwd")
 
 
 def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):

@@ -13,21 +13,37 @@ import torch.nn.functional as F
 
 from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
 from .util import dist
-from .videoqa import mask_row_logits
+from .videoqa import answer_logits
 
 
 def candidate_scores(model, tokenizer, batch_dict, device, args):
-    """mc.py:44-72,140-165: text[aid] is the batch of candidate `aid`; returns scores [B, n_candidates]."""
+    """mc.py:44-72,140-165: text[aid] is the batch of candidate `aid`; returns scores [B, n_candidates].
+
+    The reference runs one forward per candidate over the same video prefix.  Here the candidates of a batch go through
+    ONE forward of C.B samples (each candidate's token batch padded to the longest one: padding is masked, and a sample's
+    output does not depend on the rest of its batch), which fills the chip at B = 8 and, in training, needs one backward
+    instead of C.  ``args.mc_sequential = True`` keeps the reference's loop."""
     video, video_mask = video_inputs(batch_dict, device)
     text = batch_dict["text"]
-    scores = []
-    for aid in range(len(text)):  # one forward per answer candidate id
-        encoded = tokenize(tokenizer, text[aid], args)
-        output = model(video=video, video_mask=video_mask, input_ids=encoded["input_ids"].to(device),
-                       attention_mask=encoded["attention_mask"].to(device))
-        logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
-        scores.append(logits.softmax(-1)[:, 0])
-    return torch.stack(scores, 1)
+    C = len(text)
+    enc = [tokenize(tokenizer, text[aid], args) for aid in range(C)]
+    if getattr(args, "mc_sequential", False) or C == 1:
+        scores = []
+        for e in enc:  # one forward per answer candidate id
+            logits = answer_logits(model, tokenizer, e["input_ids"], args, video=video, video_mask=video_mask,
+                                   input_ids=e["input_ids"].to(device), attention_mask=e["attention_mask"].to(device))
+            scores.append(logits.softmax(-1)[:, 0])
+        return torch.stack(scores, 1)
+    Lmax = max(e["input_ids"].size(1) for e in enc)
+    B = video.size(0)
+    ids = torch.full((C * B, Lmax), tokenizer.pad_token_id, dtype=enc[0]["input_ids"].dtype)
+    att = torch.zeros((C * B, Lmax), dtype=enc[0]["attention_mask"].dtype)
+    for aid, e in enumerate(enc):
+        ids[aid * B:(aid + 1) * B, : e["input_ids"].size(1)] = e["input_ids"]
+        att[aid * B:(aid + 1) * B, : e["attention_mask"].size(1)] = e["attention_mask"]
+    logits = answer_logits(model, tokenizer, ids, args, video=video.repeat(C, 1, 1), video_mask=video_mask.repeat(C, 1),
+                           input_ids=ids.to(device), attention_mask=att.to(device))
+    return logits.softmax(-1)[:, 0].view(C, B).t()  # one [MASK] per text (mc.py:166-172)
 
 
 def mc_loss(scores, gt, n_choices):

@@ -343,7 +343,12 @@ class DebertaV2ForMaskedLM(nn.Module):
         video_mask=None,
         mlm=False,
         output_hidden_states=False,
+        logit_rows=None,
     ):
+        """Reference signature (model/deberta.py:1414-1427) plus two keyword extensions: ``output_hidden_states`` and
+        ``logit_rows`` -- int tensor of flat row indices b*S + s into the [B, S] token grid (S = video slots + text): at
+        inference the prediction head then runs on those rows only and ``logits`` is [len(logit_rows), V] (the downstream
+        loops read one [MASK] row per sample: videoqa.py:164-168, mc.py:166-170)."""
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if input_ids is None:
@@ -353,7 +358,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         if output_attentions:
             raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
         eng = self.engine()
-        res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states)
+        res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states, logit_rows=logit_rows)
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
                              attentions=None)
         run = res.get("run")

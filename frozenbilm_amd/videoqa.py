@@ -22,6 +22,23 @@ def mask_row_logits(output_logits, encoded_ids, tokenizer, args):
     return output_logits[:, delay: ids.size(1) + delay][ids == tokenizer.mask_token_id]
 
 
+def mask_rows(encoded_ids, tokenizer, args, device):
+    """Flat indices b*S + s (S = max_feats + L) of the [MASK] tokens: the rows mask_row_logits reads."""
+    delay = args.max_feats if args.use_video else 0
+    b, l = torch.nonzero(encoded_ids == tokenizer.mask_token_id, as_tuple=True)
+    return (b * (encoded_ids.size(1) + delay) + delay + l).to(device)
+
+
+def answer_logits(model, tokenizer, encoded_ids, args, **feed):
+    """Logits of the [MASK] rows, [n_mask, n_ans].  Without gradients the HIP model runs its prediction head on those rows
+    only (``logit_rows``); any other model -- or a training pass -- takes the reference's route: full logits, then
+    the row selection of videoqa.py:164-168."""
+    if hasattr(model, "engine") and not torch.is_grad_enabled():
+        rows = mask_rows(encoded_ids, tokenizer, args, feed["input_ids"].device)
+        return model(logit_rows=rows, **feed)["logits"]
+    return mask_row_logits(model(**feed)["logits"], encoded_ids, tokenizer, args)
+
+
 def vqa_loss(logits, answer_id, dataset_name):
     """videoqa.py:70-80: soft-label NLL for iVQA / VQA (answer counts /2 resp. /3, clamped to 1), CE otherwise."""
     if dataset_name in ("ivqa", "vqa"):
@@ -81,8 +98,8 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, threshol
         if not args.suffix and not args.use_context:  # remove sep token if not using the suffix (videoqa.py:152-156)
             attention_mask[input_ids == tokenizer.sep_token_id] = 0
             input_ids[input_ids == tokenizer.sep_token_id] = tokenizer.pad_token_id
-        output = model(video=video, video_mask=video_mask, input_ids=input_ids, attention_mask=attention_mask)
-        logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
+        logits = answer_logits(model, tokenizer, encoded["input_ids"], args, video=video, video_mask=video_mask,
+                               input_ids=input_ids, attention_mask=attention_mask)
         answer_id, qids = batch_dict["answer_id"].to(device), batch_dict["qid"]
         types = batch_dict["type"]
         subs = batch_dict["sub"] if "sub" in batch_dict else [0] * len(types)

@@ -66,6 +66,17 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
 int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, int64_t ldw, int M, int A, int K,
                          const float* bias, float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream);
 
+/* A dense layer and the down-projection of the adapter behind it as ONE GEMM.  wm = [W ; Wd.W] ([N1 + A, K] bf16: the
+ * lower A rows hold the adapter's down-projection composed with the dense weight -- the caller rebuilds them, with
+ * fbl_gemm_bf16_nt, whenever Wd changes), bias_m = [b ; Wd.b + bd] ([N1 + A] fp32):
+ *   y[M, N1] = x.W^T + b  -> y_f32 and/or y_bf16 (row stride ldy);   z[M, A] = dropout_p(relu(x.(Wd.W)^T + Wd.b + bd)) -> z_bf16.
+ * z equals fbl_adapter_down_fwd(y) up to bf16 rounding of the operands (y is not rounded to bf16 on the way), dropout
+ * keyed by (seed, m*ldz + a).  N1 % 4 == 0, K % 64 == 0, ldx/ldw % 8 == 0.
+ * ref: model/deberta.py:255-257, 329-331 (dense -> adapter) + model/adapter.py:38-41. */
+int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1, int A,
+                               int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
+                               uint64_t seed, void* z_bf16, int64_t ldz, void* stream);
+
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
  * (splitk_ws >= splitk*M*roundup(N,4) floats, required).  M, N, lda, ldb multiples of 8; K arbitrary.

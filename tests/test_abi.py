@@ -46,7 +46,7 @@ def test_library_exports_every_symbol(libpath):
 
     handle = lib.load(libpath)
     assert handle.fbl_abi_version() == 1
-    assert handle.fbl_ln_bwd_ws_floats(1536) == 1024 * 3 * 1536
+    assert handle.fbl_ln_bwd_ws_floats(1536) == 768 * 3 * 1536
     assert handle.fbl_colsum_ws_floats(100) == 512 * 100
 
 

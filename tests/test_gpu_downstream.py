@@ -193,3 +193,36 @@ def test_main_train_and_evaluate_loops_gpu():
     args.device_mask_tokens = True
     got2 = P_main.evaluate(m, tok, ListLoader(batches), torch.device(DEV), args)
     assert abs(got2["loss"] - got["loss"]) < 1.0 and got2["loss"] > 0
+
+
+def test_mask_row_head_and_batched_candidates_match_the_reference_shaped_path(golden):
+    """SURVEY 8(f) at speed: (1) the prediction head run on the [MASK] rows only (``logit_rows``) returns exactly the rows
+    the reference-shaped path selects from the full logits; (2) mc: all candidates of a batch in ONE forward of C.B samples
+    give the scores -- and bit-identical predicted ids -- of the reference's one-forward-per-candidate loop."""
+    g = golden("G11_mc", raw=True)
+    cfg, P, m = hip_model(2, 11, g["a2tok"])
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_mc_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_choices=4, n_batches=2, B=5, seed=311)
+    from frozenbilm_amd.loops import tokenize, video_inputs
+
+    with torch.no_grad():
+        for b in batches:
+            video, vmask = video_inputs(b, torch.device(DEV))
+            enc = tokenize(tok, b["text"][1], args)
+            feed = dict(video=video, video_mask=vmask, input_ids=enc["input_ids"].to(DEV), attention_mask=enc["attention_mask"].to(DEV))
+            full = P_vqa.mask_row_logits(m(**feed)["logits"], enc["input_ids"], tok, args)
+            rows = P_vqa.answer_logits(m, tok, enc["input_ids"], args, **feed)
+            assert rows.shape == full.shape and torch.equal(rows, full)
+            batched = P_mc.candidate_scores(m, tok, b, torch.device(DEV), args)
+            args.mc_sequential = True
+            seq = P_mc.candidate_scores(m, tok, b, torch.device(DEV), args)
+            args.mc_sequential = False
+            assert batched.shape == seq.shape == (5, 4)
+            assert (batched - seq).abs().max().item() < 2e-3  # a sample's logits do not depend on its batch (padding masked)
+            assert torch.equal(batched.max(1).indices, seq.max(1).indices)
+    # and the whole loop still reproduces the reference's results on its own golden batches
+    ref_batches = make_mc_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, n_choices=4, n_batches=3, B=4, seed=111)
+    results, acc = P_mc.evaluate(m, tok, ListLoader(ref_batches, mc=4), torch.device(DEV), "how2qa", args)
+    ref = _j(g, "eval_results")
+    flips = sum(int(results[k]["pred"] != ref[str(k)]["pred"]) for k in results)
+    assert flips <= 1, flips

@@ -698,3 +698,39 @@ def test_mask_tokens_device(L):
     assert torch.equal(o2.cpu(), out) and torch.equal(l2.cpu(), labels)
     z = orig.to(DEV); o3, l3 = mask_tokens_device(z, tok, 0.15, seed=43)
     assert not torch.equal(l3.cpu(), labels)
+
+
+@pytest.mark.parametrize("M,N1,A,K", [(300, 128, 16, 128), (4100, 1536, 192, 256), (8512, 1536, 192, 1536), (1000, 768, 96, 3072)])
+# small tiles; 8-phase 256x256 tiles (7th tile column = the bottleneck); the Wo shape of the step; a mid-size one
+def test_dense_adapter_down_merged(L, M, N1, A, K):
+    """fbl_dense_adapter_down_fwd: y = x.W^T + b and z = dropout(relu(y.Wd^T + bd)) from ONE GEMM against [W ; Wd.W]."""
+    x = bf(rnd(M, K, seed=1)).to(BF16)
+    W = bf(rnd(N1, K, seed=2, scale=0.05)).to(BF16)
+    b = rnd(N1, seed=3, scale=0.1)
+    Wd = bf(rnd(A, N1, seed=4, scale=0.05)).to(BF16)
+    bd = rnd(A, seed=5, scale=0.1)
+    # composed rows / bias the way the engine builds them (fbl_gemm_bf16_nt on W^T)
+    WT = W.t().contiguous()
+    Wm = torch.zeros(N1 + A, K, dtype=BF16, device=DEV)
+    Wm[:N1] = W
+    L.gemm(Wd, WT, out_bf16=Wm[N1:])
+    bm = torch.cat([b, Wd.float() @ b + bd]).contiguous()
+    y32 = torch.empty(M, N1, dtype=F32, device=DEV)
+    y16 = torch.empty(M, N1, dtype=BF16, device=DEV)
+    z = torch.full((M, A), 7.0, dtype=BF16, device=DEV)
+    L.dense_adapter_down_fwd(x, Wm, bm, N1, z, y_f32=y32, y_bf16=y16)
+    yref = x.float() @ W.float().t() + b
+    close(y32, yref, 1e-4, 2e-3, "y f32")
+    close(y16, yref, 1e-2, 1e-2, "y bf16")
+    zref = torch.relu(yref @ Wd.float().t() + bd)
+    close(z, zref, 2e-2, 2e-2 * max(1.0, zref.abs().max().item()), "z")
+    # dropout: same keys as fbl_dropout_bf16 on the [M, A] tensor, kept values scaled by 1/(1-p)
+    p, seed = 0.25, 1234
+    z2 = torch.empty(M, A, dtype=BF16, device=DEV)
+    L.dense_adapter_down_fwd(x, Wm, bm, N1, z2, y_f32=y32, y_bf16=y16, p_drop=p, seed=seed)
+    ones = torch.ones(M, A, dtype=BF16, device=DEV)
+    L.dropout_bf16_(ones, p, seed)
+    keep = ones.float() > 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    assert (z2.float()[~keep] == 0).all()
+    close(z2.float()[keep], z.float()[keep] / (1 - p), 2e-2, 1e-2, "kept values")
