@@ -96,12 +96,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # FBL_BENCH_SHARE_GPU=1 (test hook, never set by the driver): every rank uses cuda:0 and the collectives go through gloo,
+    # so the N > 1 code path (rank spawning, reducer, max-over-ranks timing) can be exercised on a one-GPU box.
+    share = os.environ.get("FBL_BENCH_SHARE_GPU", "0") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group("gloo" if share else "nccl", init_method="env://", world_size=world, rank=rank)
 
     from frozenbilm_amd import lib as L
     from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
@@ -363,7 +367,9 @@ def spawn_ranks(n: int) -> int:
 
 
 def measure_gemm_roofline(L, step_fn):
-    """Instrumented replay: HIP events (torch's current stream == the launch stream) around every GEMM launch of one step."""
+    """Instrumented replay: HIP events (torch's current stream == the launch stream) around every launch of the GEMM family
+    of one step (fbl_gemm_bf16_nt, fbl_dense_adapter_down_fwd, fbl_adapter_down_fwd, fbl_gemm_bf16_tn_acc), on whichever
+    stream the engine issues it."""
     import frozenbilm_amd.lib as lib
 
     recs = []
@@ -382,14 +388,31 @@ def measure_gemm_roofline(L, step_fn):
         nb = A.shape[0] if A.dim() == 3 else 1
         recs.append((s, e, 2.0 * M * N * K * nb, (M, N, K, nb)))
 
+    # the other entry points of the GEMM family: merged dense + adapter-down, stand-alone adapter-down, dW (A^T.B)
+    orig_dad, orig_ad, orig_tn = lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc
+
+    def bracket(fn, shape_of):
+        def wrapped(*a, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn(*a, **kw)
+            e.record()
+            M, N, K = shape_of(*a, **kw)
+            recs.append((s, e, 2.0 * M * N * K, (M, N, K, 1)))
+        return wrapped
+
     lib.gemm = timed
+    lib.dense_adapter_down_fwd = bracket(orig_dad, lambda x, wm, *a, **kw: (x.shape[0], wm.shape[0], x.shape[1]))
+    lib.adapter_down_fwd = bracket(orig_ad, lambda x, wd, b, z, A=None, **kw: (x.shape[0], A or wd.shape[0], x.shape[1]))
+    lib.gemm_tn_acc = bracket(orig_tn, lambda A_, B_, o, ws, M=None, N=None, K=None, **kw:
+                              (M or A_.shape[1], N or B_.shape[1], K or min(A_.shape[0], B_.shape[0])))
     try:
         step_fn()
         recs.clear()
         step_fn()
         torch.cuda.synchronize()
     finally:
-        lib.gemm = orig
+        lib.gemm, lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc = orig, orig_dad, orig_ad, orig_tn
     tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
     tot_fl = sum(f for _, _, f, _ in recs)
     by_shape = {}

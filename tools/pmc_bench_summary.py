@@ -15,7 +15,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r[ix["counter_name"]] != c:
             continue
         fam = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-        fam = fam.split("<")[0] if not fam.startswith("gemm_bf16_nt_kernel") else fam  # keep the GEMM tile/epilogue variant
+        fam = fam.replace("fblgemm::", "")
+        fam = fam.split("<")[0] if not fam.startswith("gemm") else fam  # keep the GEMM tile/epilogue variant
         res[fam][c] += float(r[ix["value"]])
         if c == "FETCH_SIZE":
             res[fam]["launches"] += 1
