@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       R.k[t] = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + sch * 8);
       R.v[t] = *(const bf16x8*)(a.v + ((long)b * S + j) * a.ldv + h * 64 + sch * 8);
     }
+    if (!(a.dbg & 16))
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = min(r_lo + srow + t * 32, a.span2 - 1);
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       lds_put(smem + SM_KS, row, sch, R.k[t]);
       *(bf16x8*)(smem + SM_VT + row * (LDV * 2) + sch * 16) = R.v[t];
     }
+    if (!(a.dbg & 16))
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int row = srow + t * 32;

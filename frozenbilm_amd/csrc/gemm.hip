@@ -460,23 +460,49 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       const int tm_big = (int)((total - rem) / tn);             // whole rounds worth of M tiles
       const int m_big = tm_big * 256;
       if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
-        int rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
-                              out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
-                              p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0);
-        if (rc) return rc;
+        // FBL_GEMM_REM bit 0: the remainder rows run on a helper stream, launched BEFORE the big tiles (fork / join by
+        // events): its workgroups take their CUs first, so those CUs reach their first big tile a fraction of a tile late
+        // -- the chip leaves lockstep (the epilogue of a round is an HBM burst: every CU stores its tile at the same moment
+        // while the memory system idles during the main loops) and the remainder costs no round of its own.
+        // bit 1: remainder in 64x128 tiles (320 rows x 6144: 240 workgroups instead of 144).
+        static const int rem_mode = getenv("FBL_GEMM_REM") ? atoi(getenv("FBL_GEMM_REM")) : 3;
+        static hipStream_t rem_stream = nullptr;
+        static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        bool forked = false;
+        if ((rem_mode & 1) && !rem_stream) {
+          if (hipStreamCreateWithFlags(&rem_stream, hipStreamNonBlocking) != hipSuccess ||
+              hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return FBL_ERR_ARG;
+        }
+        void* s_rem = stream;
+        if (rem_mode & 1) {
+          if (hipEventRecord(ev_fork, (hipStream_t)stream) != hipSuccess) return FBL_ERR_ARG;
+          if (hipStreamWaitEvent(rem_stream, ev_fork, 0) != hipSuccess) return FBL_ERR_ARG;
+          s_rem = (void*)rem_stream;
+          forked = true;
+        }
         const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
-        return gemm_nt_impl((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
-                                rowscale ? rowscale + m_big : nullptr, alpha, act, aux_kind,
-                                aux ? (const char*)aux + (size_t)m_big * ld_aux * aux_es : nullptr, ld_aux,
-                                out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
-                                out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
-                                out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
-                                1, nullptr, -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, stream, seg_n,
-                                seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big);
+        int rc = gemm_nt_impl((const char*)A + (size_t)m_big * lda * 2, lda, B, ldb, M - m_big, N, K, bias,
+                              rowscale ? rowscale + m_big : nullptr, alpha, act, aux_kind,
+                              aux ? (const char*)aux + (size_t)m_big * ld_aux * aux_es : nullptr, ld_aux,
+                              out_f32 ? out_f32 + (size_t)m_big * ldc : nullptr,
+                              out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
+                              out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
+                              1, nullptr, (rem_mode & 2) ? -3 : -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, s_rem, seg_n,
+                              seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big);
+        if (rc) return rc;
+        if (forked && hipEventRecord(ev_join, rem_stream) != hipSuccess) return FBL_ERR_ARG;
+        rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
+                          out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
+                          p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0);
+        if (rc) return rc;
+        if (forked && hipStreamWaitEvent((hipStream_t)stream, ev_join, 0) != hipSuccess) return FBL_ERR_ARG;
+        return 0;
       }
     }
   }
-  const bool use_big = big && splitk_ws_floats != -2;  // -2: remainder rows of a split launch -> 128x128 tiles
+  const bool use_big = big && splitk_ws_floats > -2;  // -2 / -3: remainder rows of a split launch -> 128x128 / 64x128 tiles
   const int BT = use_big ? 256 : 128;
   // 224x256 tiles when they cover the problem in fewer (rounds x tile area) than 256x256 -- the N = 1536 GEMMs of the
   // step: 38 x 6 = 228 tiles in one round instead of 204 tiles that are 14 % bigger
@@ -499,7 +525,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   // 64x128 tiles for tall, narrow problems whose 128x128 grid covers less than the chip (the adapter bottleneck
   // projections: 8512 x 192 -> 134 workgroups): twice the workgroups, so twice the CUs pull operands from L2
   static const int no64 = getenv("FBL_GEMM_NO64") ? atoi(getenv("FBL_GEMM_NO64")) : 0;
-  const bool use_64 = !use_big && !accumulate && !no64 && batch == 1 && M >= 2048 && splitk_ws_floats >= 0 &&
+  const bool use_64 = !use_big && !accumulate && !no64 && batch == 1 &&
+                      ((M >= 2048 && splitk_ws_floats >= 0) || splitk_ws_floats == -3) &&
                       (long)((M + 127) / 128) * ((N + 127) / 128) < 200;
   g.tiles_m = use_224 ? (M + 223) / 224 : use_64 ? (M + 63) / 64 : (M + BT - 1) / BT;
   g.tiles_n = (N + BT - 1) / BT;
