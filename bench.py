@@ -15,9 +15,11 @@ asked").  `--full-logits` reads `.logits` in every step (the reference's eager b
 a few such steps and reports them as `with_full_logits`.  FLOP figures always use the reference-faithful op list.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline     -- the dominant kernel family (bf16 MFMA GEMM): algorithmic FLOPs of its launches in one step / their
-                  summed HIP-event durations (measured live on the launch stream in an instrumented replay of the same
-                  step), against the 2.5 PFLOP/s dense bf16 peak; `executed_tflops_per_step` discloses what ran.
+  roofline     -- the dominant kernel (gemm8_kernel, the 8-phase 256x256 bf16 MFMA GEMM: ~45 % of the step's kernel time):
+                  algorithmic FLOPs of its launches in one step / their summed HIP-event durations (measured live on the
+                  launch stream in an instrumented replay of the same step), against the 2.5 PFLOP/s dense bf16 peak.
+                  `family` inside it gives the same figures over EVERY launch of the GEMM family (small / split-K / dW
+                  kernels included -- the round-1 definition), `executed_gemm_tflops_per_step` discloses what ran.
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this box's host cores on a
                   bounded sample (B=2 sequences of the same shape, 1 warm-up + timed passes,
                   fwd+bwd, threads = physical cores), rank 0, N=1 only.
@@ -386,23 +388,24 @@ def measure_gemm_roofline(L, step_fn):
         N = kw.get("N") or B2.shape[0]
         K = kw.get("K") or A2.shape[1]  # (k-blocked A operands pass the true contraction length explicitly)
         nb = A.shape[0] if A.dim() == 3 else 1
-        recs.append((s, e, 2.0 * M * N * K * nb, (M, N, K, nb)))
+        big = nb == 1 and kw.get("splitk", 1) <= 1 and _takes_gemm8(M, N, K)
+        recs.append((s, e, 2.0 * M * N * K * nb, (M, N, K, nb), big))
 
     # the other entry points of the GEMM family: merged dense + adapter-down, stand-alone adapter-down, dW (A^T.B)
     orig_dad, orig_ad, orig_tn = lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc
 
-    def bracket(fn, shape_of):
+    def bracket(fn, shape_of, big_ok=False):
         def wrapped(*a, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             fn(*a, **kw)
             e.record()
             M, N, K = shape_of(*a, **kw)
-            recs.append((s, e, 2.0 * M * N * K, (M, N, K, 1)))
+            recs.append((s, e, 2.0 * M * N * K, (M, N, K, 1), big_ok and _takes_gemm8(M, N, K)))
         return wrapped
 
     lib.gemm = timed
-    lib.dense_adapter_down_fwd = bracket(orig_dad, lambda x, wm, *a, **kw: (x.shape[0], wm.shape[0], x.shape[1]))
+    lib.dense_adapter_down_fwd = bracket(orig_dad, lambda x, wm, *a, **kw: (x.shape[0], wm.shape[0], x.shape[1]), big_ok=True)
     lib.adapter_down_fwd = bracket(orig_ad, lambda x, wd, b, z, A=None, **kw: (x.shape[0], A or wd.shape[0], x.shape[1]))
     lib.gemm_tn_acc = bracket(orig_tn, lambda A_, B_, o, ws, M=None, N=None, K=None, **kw:
                               (M or A_.shape[1], N or B_.shape[1], K or min(A_.shape[0], B_.shape[0])))
@@ -413,37 +416,57 @@ def measure_gemm_roofline(L, step_fn):
         torch.cuda.synchronize()
     finally:
         lib.gemm, lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc = orig, orig_dad, orig_ad, orig_tn
-    tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-    tot_fl = sum(f for _, _, f, _ in recs)
+    def summary(rs):
+        ms = sum(s.elapsed_time(e) for s, e, *_ in rs)
+        fl = sum(r[2] for r in rs)
+        return ms, fl, (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+
+    dom = [r for r in recs if r[4]]
+    dom_ms, dom_fl, dom_ach = summary(dom)
+    tot_ms, tot_fl, ach = summary(recs)
     by_shape = {}
-    for s, e, f, shp in recs:
+    for s, e, f, shp, big in recs:
         d = by_shape.setdefault(shp, [0, 0.0, 0.0])
         d[0] += 1
         d[1] += s.elapsed_time(e)
         d[2] += f
     top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:8]
-    ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    # HBM-side bytes of the same kernel family over the same step come from separate rocprofv3 --pmc passes (FETCH_SIZE
-    # x2 for gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/*_traffic.json): PMC passes cannot run inside this
-    # process, so the newest COMMITTED summary is read back and divided by this run's GEMM call count ("source" says so).
-    traffic, traffic_src = None, None
+    # HBM-side bytes of the same kernels over the same step come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 for
+    # gfx950 + WRITE_SIZE; tools/pmc_bench.sh -> profiles/*_traffic.json): PMC passes cannot run inside this process, so
+    # the newest COMMITTED summary is read back ("source" says so).
+    traffic, traffic_src, fam_gb = None, None, None
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     cands = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
     if cands and recs:
         with open(os.path.join(pdir, cands[-1])) as f:
             tj = json.load(f)
-        gb = sum(v["GB_per_step"] for k, v in tj.items() if k.startswith("gemm"))
-        traffic = gb * 1e9 / len(recs)
-        traffic_src = ("committed: profiles/%s -- %.1f GB/step over the GEMM kernel family (rocprofv3 --pmc FETCH_SIZE, "
-                       "WRITE_SIZE passes over this command at the commit that wrote the file), bytes per GEMM call; not "
-                       "re-measured by this run" % (cands[-1], gb))
-    return {"bound": "mfma", "kernel": "gemm8_kernel / gemm_bf16_nt_kernel (bf16 MFMA GEMM family)", "achieved": ach,
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-            "traffic_source": traffic_src, "launches_per_step": len(recs),
-            "avg_launch_us": tot_ms * 1e3 / max(len(recs), 1), "gemm_ms_per_step": tot_ms,
-            "executed_gemm_tflops_per_step": tot_fl / 1e12,
+        fam_gb = sum(v["GB_per_step"] for k, v in tj.items() if k.startswith("gemm"))
+        d8 = [v for k, v in tj.items() if k.startswith("gemm8_kernel")]
+        if d8:
+            traffic = sum(v["GB_per_step"] for v in d8) * 1e9 / sum(v["launches_per_step"] for v in d8)
+            traffic_src = ("committed: profiles/%s -- %.1f GB/step over %d gemm8_kernel launches (rocprofv3 --pmc FETCH_SIZE, "
+                           "WRITE_SIZE passes over this command at the commit that wrote the file), bytes per launch; not "
+                           "re-measured by this run" % (cands[-1], sum(v["GB_per_step"] for v in d8),
+                                                        round(sum(v["launches_per_step"] for v in d8))))
+    return {"bound": "mfma", "kernel": "gemm8_kernel (8-phase 256x256 / 224x256 bf16 MFMA GEMM, all epilogues; a split launch "
+                                       "includes its 64x128-tile remainder)",
+            "achieved": dom_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom_ach / PEAK_BF16_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(dom),
+            "avg_launch_us": dom_ms * 1e3 / max(len(dom), 1), "kernel_ms_per_step": dom_ms,
+            "algorithmic_tflops_per_step": dom_fl / 1e12,
+            "family": {"what": "every launch of the GEMM family (gemm8_kernel, gemm_bf16_nt_kernel incl. split-K / batched "
+                               "position-table products, gemm_bf16_tn_kernel dW)", "achieved": ach,
+                       "frac": ach / PEAK_BF16_TFLOPS, "launches_per_step": len(recs), "gemm_ms_per_step": tot_ms,
+                       "hbm_gb_per_step_committed": fam_gb},
+            "gemm_ms_per_step": tot_ms, "executed_gemm_tflops_per_step": tot_fl / 1e12,
             "top_shapes_MNKb_count_ms_tflops": [[list(k), v[0], round(v[1], 3), round(v[2] / (v[1] * 1e-3) / 1e12, 1)]
                                                 for k, v in top]}
+
+
+def _takes_gemm8(M, N, K):
+    """mirror of the dispatcher in csrc/gemm.hip (`big` and gemm8_eligible): which plain launches the 8-phase kernel takes"""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return M >= 2048 and N >= 1024 and tiles >= 128 and K % 64 == 0 and (K // 64) % 2 == 0 and K // 64 >= 4
 
 
 def measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only):
