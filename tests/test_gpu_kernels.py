@@ -42,7 +42,7 @@ def close(got, ref, rtol, atol, name=""):
                                    (130, 6, 64), (4100, 2052, 128), (8512, 1536, 192), (4100, 3584, 128), (8512, 192, 1536),
                                    (2100, 70, 64), (4100, 3500, 256), (4100, 3584, 1536), (8512, 6144, 384), (8512, 1536, 384), (4100, 2052, 256)])
 # (4100,35xx,K>=256): the 8-phase 256x256 kernel (gemm8.hip; K = 256 is its shortest pipeline, N = 3500 a ragged last column
-# tile); (8512,6144): 8-phase tiles for the whole rounds + 128x128 tiles for the remaining rows; (8512,1536,384) and
+# tile); (8512,6144): 8-phase tiles for the whole rounds + 64x128 tiles for the remaining rows (helper stream); (8512,1536,384) and
 # (4100,2052,256): 224-row 8-phase tiles (second wave row with three 16-row MFMA tiles per half);
 # (4100,2052) and (8512,1536): 224x256 tiles (fewer rounds x area); (4100,3584): 256x256 tiles (238 tiles, one round);
 # (8512,192) and (2100,70): 64x128 tiles (tall and narrow: the 128x128 grid would not cover the chip)
