@@ -464,9 +464,10 @@ def measure_gemm_roofline(L, step_fn):
 
 
 def _takes_gemm8(M, N, K):
-    """mirror of the dispatcher in csrc/gemm.hip (`big` and gemm8_eligible): which plain launches the 8-phase kernel takes"""
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    return M >= 2048 and N >= 1024 and tiles >= 128 and K % 64 == 0 and (K // 64) % 2 == 0 and K // 64 >= 4
+    """launches the dispatcher of csrc/gemm.hip gives to the 8-phase kernel (the library's own host-side query)"""
+    import frozenbilm_amd.lib as lib
+
+    return lib.gemm_plan(M, N, K) == 8
 
 
 def measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only):

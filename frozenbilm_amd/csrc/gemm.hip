@@ -334,6 +334,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmTnArgs g) {
   }
 }
 
+// 256x256 (or 224x256) tiles only where both dimensions fill them and the grid still covers half the chip
+static inline bool big_tile_shape(int M, int N, int batch) {
+  return batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
+}
+
 // out[b][m][n] += sum_ks ws[b][ks][m][n]   (deterministic split-K fold)
 __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, int Nw, float* out, long ldc, long sC) {
   const int b = blockIdx.y;
@@ -420,8 +425,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
-  const bool big = !force_small && !accumulate && batch == 1 && (p_drop <= 0.f || seg_n > 0) && M >= 2048 && N >= 1024 &&
-                   ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
+  const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0) && big_tile_shape(M, N, batch);
   // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
   // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
   // the CUs the last round does not need start up to 0.4 tiles late, which costs no wall time and takes the CUs out of
@@ -633,6 +637,17 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   }
   FBL_CHECK_LAUNCH();
   return 0;
+}
+
+// Host-side query (no launch): which kernel fbl_gemm_bf16_nt gives a plain launch of this shape to -- 8: the 8-phase
+// kernel of gemm8.hip (whole rounds; a remainder of rows may go to 64x128 tiles of the 2-stage kernel), 2: the 2-stage kernel.
+extern "C" int fbl_gemm_plan(int M, int N, int K, int batch, int splitk) {
+  static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
+  static const int gemm8_on = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
+  if (force_small || gemm8_on <= 0 || splitk > 1 || !big_tile_shape(M, N, batch)) return 2;
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.splitk = 1;
+  return gemm8_eligible(g) ? 8 : 2;
 }
 
 extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

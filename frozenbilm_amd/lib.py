@@ -28,6 +28,7 @@ SIGNATURES = {
     "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                         _vp]),
     "fbl_ln_materialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
@@ -112,6 +113,11 @@ def _rows2d(t: torch.Tensor, name: str):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+def gemm_plan(M, N, K, batch=1, splitk=1):
+    """8 if fbl_gemm_bf16_nt runs this plain problem on the 8-phase kernel (gemm8_kernel), 2 for the 2-stage kernel"""
+    return load().fbl_gemm_plan(int(M), int(N), int(K), int(batch), int(splitk))
+
+
 def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, aux_kind=AUX_NONE, out_f32=None,
          out_bf16=None, out_pre=None, splitk=1, M=None, N=None, ws=None, K=None, a_kblock=0, kskip_len=None, kskip_steps=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B: bf16 2-D views (or 3-D for strided batch)."""

@@ -57,6 +57,11 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len,
                      int kskip_steps, void* stream);
 
+/* Host-side query, no launch: the kernel fbl_gemm_bf16_nt uses for a plain (K-contiguous, no k-skip) problem of this
+ * shape: 8 = the 8-phase 256x256 / 224x256 kernel (gemm8_kernel; remainder rows of a multi-round problem run as 64x128
+ * tiles), 2 = the 2-stage 128x128 / 64x128 kernel.  bench.py attributes launches to the dominant kernel with it. */
+int fbl_gemm_plan(int M, int N, int K, int batch, int splitk);
+
 /* Adapter down-projection with the whole bottleneck non-linearity in the GEMM epilogue:
  *   z[M, A] = dropout_p( relu( x[M,K] . Wd[A,K]^T + bd ) )        (bf16 MFMA, fp32 accumulate, bf16 out)
  * Dropout is the counter-based one of fbl_dropout_bf16: element (m, a) is keyed by (seed, m*ldz + a), dropped elements

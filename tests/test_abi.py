@@ -64,3 +64,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_gemm_plan_host_query(libpath):
+    """fbl_gemm_plan is pure host logic (no launch, no GPU): the shapes of the step that the dispatcher gives to the
+    8-phase kernel -- what bench.py's `roofline` attributes to the dominant kernel -- and the ones it does not."""
+    from frozenbilm_amd import lib as L
+
+    for shp in [(8512, 6144, 1536), (9024, 4608, 1536), (8512, 1536, 6144), (8512, 1728, 6144), (8512, 1536, 1536),
+                (8512, 1536, 4608), (8512, 128100, 1536)]:
+        assert L.gemm_plan(*shp) == 8, shp
+    for shp in [(8512, 1536, 192), (8512, 192, 1536), (391, 64, 10240), (4100, 3584, 128), (512, 1536, 3072),
+                (8512, 1536, 1600)]:
+        assert L.gemm_plan(*shp) == 2, shp
+    assert L.gemm_plan(8512, 6144, 1536, batch=2) == 2 and L.gemm_plan(8512, 6144, 1536, splitk=4) == 2
