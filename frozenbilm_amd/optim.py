@@ -4,6 +4,11 @@ Drop-in for ``torch.optim.Adam(params_requiring_grad, lr, betas, weight_decay)``
 (main.py:182-188) followed by ``clip_grad_norm_(model.parameters(), max_norm)`` (main.py:82-84): pass
 ``clip_max_norm`` to ``step`` to fold the global-norm clip into the update.  ``param_groups[0]["lr"]`` is honoured so
 ``adjust_learning_rate`` (util/misc.py:59-78) keeps working.
+
+One deliberate difference from ``torch.optim.Adam``: the update runs over the whole flat trainable buffer with ONE step
+counter, so a parameter whose gradient is identically zero in a step (``linear_video`` on a batch without video -- no
+loop of the reference produces one) still sees its moments decay and moves by ``lr * m_hat / (sqrt(v_hat) + eps)``,
+whereas torch skips parameters whose ``.grad`` is None.  Exported states carry the common step count for every parameter.
 """
 from __future__ import annotations
 
