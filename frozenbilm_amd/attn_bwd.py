@@ -30,6 +30,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     pq, pk = sv.pqk[:, :H], sv.pqk[:, H:]
     relidx = eng.relidx(S)
     klen = getattr(run, "klen", None)
+    border = getattr(run, "border", None)
     scale = 1.0 / math.sqrt(64 * 3)
 
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
@@ -40,8 +41,6 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
-    L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
-                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
@@ -52,6 +51,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     rmin, rcnt = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1) if rv is not None else (0, span2)
     # |i-j| < lin: identity buckets, relidx injective (model/deberta.py:578-589: mid = bucket_size // 2)
     lin = 0 if rv is None else (eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30)
+    lin_a = min(lin, span2 // 2) if eng.cfg.position_buckets > 0 else 0  # affine addressing of kernel A: identity buckets only
+    L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
+                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a)
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
     G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
@@ -59,9 +61,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
         G1T.fill_(float("nan"))
         G2T.fill_(float("nan"))
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
-                            lin=lin)
+                            lin=lin, border=border)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
-                            rcnt=rcnt, lin=lin)
+                            rcnt=rcnt, lin=lin, border=border)
     del dS, dST
     state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen)
     if defer_pos:

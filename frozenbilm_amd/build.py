@@ -16,10 +16,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "build")
-LIB = os.path.join(HERE, "libfbl.so")
+# FBL_DEBUG_BUILD=1 builds the measurement variant libfbl_dbg.so (-DFBL_DEBUG_SWITCHES: the FBL_* experiment switches of
+# the dispatchers are live; frozenbilm_amd.lib loads it only when FBL_LIB points at it).  The product library has none.
+DEBUG = os.environ.get("FBL_DEBUG_BUILD", "0") == "1"
+OBJ = os.path.join(HERE, "csrc", "build_dbg" if DEBUG else "build")
+LIB = os.path.join(HERE, "libfbl_dbg.so" if DEBUG else "libfbl.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+if DEBUG:
+    FLAGS.append("-DFBL_DEBUG_SWITCHES")
 
 
 def _hipcc() -> str:

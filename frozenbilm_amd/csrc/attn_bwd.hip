@@ -13,7 +13,7 @@
 //            columns, so dV accumulates in registers; writes dS and dS^T (bf16, zero where masked) -- 2 x SxS bf16 per
 //            head is the only extra HBM.  Next query tile prefetched into registers while the current one is computed.
 // Kernel BC (attn_bwd_shear<NEG>): one workgroup per (b, h, 32 rows): X_out = dSx.Y + G.Ptab with the scatter
-//            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS atomics (ds_add_f32) into a [32 x W] fp32 tile, W =
+//            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS stores / atomics into a [32 x W] bf16 tile, W =
 //            the index range the 32 rows can reach (~S+32 <= 512); also writes G^T for the position-table GEMMs.
 #include "attn_common.h"
 #include "../../include/fbl.h"
@@ -53,60 +53,81 @@ struct BwdAArgs {
   const bf16* q; const bf16* k; const bf16* v; long ldq;  // row-major [B*S, ld], head h at col h*64
   const bf16* dO; long ldo;                               // row-major [B*S, ldo]
   const bf16* pk; const bf16* pq; long ldp;
-  const int16_t* relidx; const int32_t* mask; const int32_t* klen;
+  const int16_t* relidx; const int32_t* mask; const int32_t* klen; const int32_t* border;
   const float* lse; const float* Dv;                      // [B,nh,S]
   float scale, p_drop; uint64_t seed;
   bf16* dV; long lddv;                                    // row-major out, head h at col h*64
   bf16* dS; bf16* dST;                                    // [B,nh,Sp,Sp]
   int B, S, Sp, nh, span2;
+  int lin;  // |d| < lin: idx(d) = idx(0) + d (identity buckets); 0 = unknown
 };
 
+// LDS: Q, dO tiles (per iteration) and this workgroup's K tile 3 x 8 KiB, T1 / T2 2 x 13 KiB (reused as the dS / dS^T
+// staging tiles), per-row lse / D, key validity, index table = 52.5 KiB at Sp = 320: three workgroups per CU.  As in the
+// forward (attn_fwd.hip) the position tables are not staged: each wave owns two of the eight 16-row tiles of the pair's
+// table window, loads their MFMA A-fragments from global memory once and multiplies them against every query group
+// (T1) and key group (T2) whose sub-window contains the tile.
+constexpr int LTW = 104;                         // fp16 row stride of the T1/T2 tiles (6 row tiles = 96 used)
 constexpr int A_QS = 0;                          // [64 i][64] swz
 constexpr int A_DOS = A_QS + 8192;               // [64 i][64] swz
-constexpr int A_PK = A_DOS + 8192;               // [128][64] swz
-constexpr int A_PQ = A_PK + 16384;
-constexpr int A_T1 = A_PQ + 16384;               // [64 i][LT] fp16 (shared)  -- reused as the [64][72] bf16 dS staging tile
-constexpr int A_T2 = A_T1 + 64 * LT * 2;         // [4][16][LT] fp16 (wave private, per key)
-constexpr int A_IDX = A_T2 + 64 * LT * 2;        // int16[1024]
-constexpr int A_ROW = A_IDX + 2048;              // float lse[64], D[64], qvalid[64]
-constexpr int A_TOTAL = A_ROW + 768;
-static_assert(64 * LT * 2 >= 64 * LDV * 2, "dS staging tile must fit in the T1 region");
+constexpr int A_KS = A_DOS + 8192;               // [64 j][64] swz (staged once)
+constexpr int A_T1 = A_KS + 8192;                // [64 i][LTW] fp16 -- reused as the [64][72] bf16 dS staging tile
+constexpr int A_T2 = A_T1 + 64 * LTW * 2;        // [64 j][LTW] fp16 -- reused as the dS^T staging tile
+constexpr int A_ROW = A_T2 + 64 * LTW * 2;       // float lse[64], D[64], key validity[64]
+constexpr int A_IDX = A_ROW + 768;               // int16[2*Sp]
+__host__ __device__ constexpr int a_total(int Sp) { return A_IDX + 2 * Sp * 2; }
+static_assert(64 * LTW * 2 >= 64 * LDV * 2, "dS staging tile must fit in the T1 region");
 
 struct ATileRegs {
-  bf16x8 q[2], d[2], pk[4], pq[4];
+  bf16x8 q[2], d[2];
   float lse, D;
 };
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int S = a.S, Sp = a.Sp;
+  const WgCoord wc = wg_coord(Sp / 64, a.nh, a.B, a.border);
+  const int j0 = wc.x * 64, h = wc.h, b = wc.b;
   const int j = j0 + w * 16 + c;  // this lane's key
   const int jc = min(j, S - 1);
   const int tq = Sp - 1;  // idx[i - j + tq]
 
   int16_t* idx = (int16_t*)(smem + A_IDX);
   f16* T1 = (f16*)(smem + A_T1);
-  f16* T2w = (f16*)(smem + A_T2) + w * 16 * LT;
+  f16* T2 = (f16*)(smem + A_T2);
   float* rlse = (float*)(smem + A_ROW);
   float* rD = rlse + 64;
+  float* kms = rlse + 128;
   bf16* dst = (bf16*)(smem + A_T1);   // dS tile [query][key] after the gather
   bf16* dstT = (bf16*)(smem + A_T2);  // dS^T tile [key][query]
 
-  load_idx_padded(idx, a.relidx, S, Sp, tid, 256);
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;  // tiles beyond the last valid position: dS = 0 (never read), dV = 0
+  const int srow = tid >> 3, sch = tid & 7;
+  // LDS addressing as lane constants + immediates (see attn_fwd.hip)
+  const int fb0 = c * 128 + ((g ^ (c & 7)) << 4), fb1 = fb0 ^ 64;  // fragment of row x*16 + c: + x*2048
+  const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);           // staging slot of row srow + 32 t: + t*4096
 
-  bf16x8 kf[2], vf[2];
+  bf16x8 vf[2];  // V fragments of this lane's key (the K fragments are read from the K tile in LDS where they are used)
   {
     const long off = ((long)b * S + jc) * a.ldq + h * 64 + g * 8;
-    kf[0] = *(const bf16x8*)(a.k + off);
-    kf[1] = *(const bf16x8*)(a.k + off + 32);
     vf[0] = *(const bf16x8*)(a.v + off);
     vf[1] = *(const bf16x8*)(a.v + off + 32);
   }
-  const bool kvalid = j < S && a.mask[(long)b * S + jc] != 0;
+  if (nqt > 0) {
+    load_idx_padded(idx, a.relidx, S, Sp, tid, 256);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      *(bf16x8*)(smem + A_KS + sb + t * 4096) =
+          *(const bf16x8*)(a.k + ((long)b * S + min(j0 + srow + t * 32, S - 1)) * a.ldq + h * 64 + sch * 8);
+    if (tid < 64) kms[tid] = (j0 + tid < S && a.mask[(long)b * S + min(j0 + tid, S - 1)] != 0) ? 1.f : 0.f;
+    // T1 / T2 slots that no row tile of a pair covers are still gathered by padding rows / columns (whose P is forced
+    // to 0 through lse = +inf or a -inf T2 row): they must hold finite-or--inf values, never NaN bit patterns
+    for (int t = tid; t < (2 * 64 * LTW * 2) / 16; t += 256) *(bf16x8*)(smem + A_T1 + t * 16) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
 
   f32x4 dv[4];
 #pragma unroll
@@ -114,11 +135,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
   const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
   const float k2 = a.scale * LOG2E;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
-  const int kl = a.klen ? min(a.klen[b], S) : S;
-  const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;  // tiles beyond the last valid position: dS = 0 (never read), dV = 0
-  __syncthreads();
+  const int izero = a.relidx[S - 1];  // idx(0)
+  const bf16* pkh = a.pk + h * 64 + g * 8;
+  const bf16* pqh = a.pq + h * 64 + g * 8;
+  const int my_t0 = (0x5243 >> (w * 4)) & 15, my_t1 = (0x1670 >> (w * 4)) & 15;  // this wave's window row tiles
 
-  const int srow = tid >> 3, sch = tid & 7;
   auto load_qd = [&](int it, ATileRegs& R) {
     const int i0 = it * 64;
 #pragma unroll
@@ -137,27 +158,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       }
     }
   };
-  auto load_win = [&](int it, ATileRegs& R) {  // issued late in the iteration: keeps 32 VGPRs free during the gather
-    const int i0 = it * 64;
-    const int r_lo = idx[i0 - (j0 + 63) + tq];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = min(r_lo + srow + t * 32, a.span2 - 1);
-      const long off = (long)r * a.ldp + h * 64 + sch * 8;
-      R.pk[t] = *(const bf16x8*)(a.pk + off);
-      R.pq[t] = *(const bf16x8*)(a.pq + off);
-    }
-  };
   auto store_tile = [&](const ATileRegs& R) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      lds_put(smem + A_QS, srow + t * 32, sch, R.q[t]);
-      lds_put(smem + A_DOS, srow + t * 32, sch, R.d[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      lds_put(smem + A_PK, srow + t * 32, sch, R.pk[t]);
-      lds_put(smem + A_PQ, srow + t * 32, sch, R.pq[t]);
+      *(bf16x8*)(smem + A_QS + sb + t * 4096) = R.q[t];
+      *(bf16x8*)(smem + A_DOS + sb + t * 4096) = R.d[t];
     }
     if (tid < 64) {
       rlse[tid] = R.lse;
@@ -165,66 +170,123 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
     }
   };
 
-  ATileRegs R;
-  if (nqt > 0) {
-    load_qd(0, R);
-    load_win(0, R);
-  }
   for (int it = 0; it < nqt; ++it) {
     const int i0 = it * 64;
-    const int r_lo = idx[i0 - (j0 + 63) + tq];
-    store_tile(R);
-    __syncthreads();
-    if (it + 1 < nqt) load_qd(it + 1, R);
-    // sub-window offsets: this wave's 16 keys (T2) and each 16-query tile (T1)
-    const int base2 = idx[i0 - (j0 + w * 16 + 15) + tq];  // absolute table row of T2w[.][0]
-    const int off2 = base2 - r_lo;
-    int base1[4];                                          // absolute table row of T1[query tile nt][.][0]
+    const bool band = max(abs(i0 - (j0 + 63)), abs(i0 + 63 - j0)) < a.lin;
+    int r_lo, t0q[4], t0k[4];
+    if (band) {
+      r_lo = izero + i0 - (j0 + 63);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) base1[nt] = idx[i0 + nt * 16 - (j0 + 63) + tq];
-    const int off1w = idx[i0 + w * 16 - (j0 + 63) + tq] - r_lo;
+      for (int x = 0; x < 4; ++x) { t0q[x] = x; t0k[x] = 3 - x; }
+    } else {
+      if (it == 0) __syncthreads();  // index table
+      r_lo = __builtin_amdgcn_readfirstlane((int)idx[i0 - (j0 + 63) + tq]);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        t0q[x] = (__builtin_amdgcn_readfirstlane((int)idx[i0 + x * 16 - (j0 + 63) + tq]) - r_lo) >> 4;
+        t0k[x] = (__builtin_amdgcn_readfirstlane((int)idx[i0 - (j0 + x * 16 + 15) + tq]) - r_lo) >> 4;
+      }
+    }
+    const int ntile = band ? 5 : 6;
+    bf16x8 apk[2][2], apq[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long ro = (long)min(r_lo + (u ? my_t1 : my_t0) * 16 + c, a.span2 - 1) * a.ldp;
+      apk[u][0] = *(const bf16x8*)(pkh + ro);
+      apk[u][1] = *(const bf16x8*)(pkh + ro + 32);
+      apq[u][0] = *(const bf16x8*)(pqh + ro);
+      apq[u][1] = *(const bf16x8*)(pqh + ro + 32);
+    }
+    {
+      ATileRegs R;
+      load_qd(it, R);  // no register prefetch: the other workgroups of the CU cover the load latency
+      store_tile(R);
+    }
+    __syncthreads();
 
     // ---- (1) scores: sacc[nt][r] = Q_i . K_j,  i = i0 + nt*16 + g*4 + r, key column c
     f32x4 sacc[4];
+    const bf16x8 kf[2] = {*(const bf16x8*)(smem + A_KS + w * 2048 + fb0), *(const bf16x8*)(smem + A_KS + w * 2048 + fb1)};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_QS, nt * 16 + c, g), kf[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_QS, nt * 16 + c, 4 + g), kf[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + A_QS + nt * 2048 + fb0), kf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + A_QS + nt * 2048 + fb1), kf[1], acc, 0, 0, 0);
       sacc[nt] = acc;
     }
-    // ---- (2) T2 for this wave's keys (private), T1 for query tile w (shared)
-    bias_tile(smem + A_PQ, off2, kf[0], kf[1], T2w + c * LT, c, g, kvalid);  // masked key: T2 row = -inf -> P = 0
-    bias_tile(smem + A_PK, off1w, lds_frag(smem + A_QS, w * 16 + c, g), lds_frag(smem + A_QS, w * 16 + c, 4 + g),
-              T1 + (w * 16 + c) * LT, c, g);
+    // ---- (2) this wave's row tiles of T1[query][.] = Q_i . PK[.] and T2[key][.] = K_j . PQ[.]  (fp16, as the forward)
+    {
+      const f16 ninf = (f16)(-INFINITY);
+      f16* t1s = T1 + c * LTW + g * 4;  // + (x*16)*LTW + rel*16
+      f16* t2s = T2 + c * LTW + g * 4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = u ? my_t1 : my_t0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int rel1 = t - t0q[x];
+          if (rel1 >= 0 && rel1 < ntile) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apk[u][0], *(const bf16x8*)(smem + A_QS + x * 2048 + fb0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apk[u][1], *(const bf16x8*)(smem + A_QS + x * 2048 + fb1), acc, 0, 0, 0);
+            *(f16x4*)(t1s + x * 16 * LTW + rel1 * 16) = to_f16x4(acc);
+          }
+          const int rel2 = t - t0k[x];
+          if (rel2 >= 0 && rel2 < ntile) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apq[u][0], *(const bf16x8*)(smem + A_KS + x * 2048 + fb0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apq[u][1], *(const bf16x8*)(smem + A_KS + x * 2048 + fb1), acc, 0, 0, 0);
+            const f16x4 tv = to_f16x4(acc);
+            // masked / padding keys: T2 row = -inf -> P = 0
+            *(f16x4*)(t2s + x * 16 * LTW + rel2 * 16) = kms[x * 16 + c] != 0.f ? tv : (f16x4){ninf, ninf, ninf, ninf};
+          }
+        }
+      }
+    }
     __syncthreads();
 
-    // ---- (3) P (same arithmetic as the forward).  The window offsets are clamped here (one v_med3 each): padding
-    // queries must give an exact P = 0 (finite score, lse = +inf), not garbage, because their dS rows are stored.
+    // ---- (3) P (same arithmetic as the forward)
     float p[16];
-    {
+    if (band) {
+      // c2p: T1[i][(i - j) - (r_lo + 16 nt - izero)] = T1[nt*16 + g*4 + r][g*4 + r + 63 - 16 w - c]
+      // p2c: T2[j][(i - j) - (r_lo + 16 (3 - w) - izero)] = T2[16 w + c][nt*16 + g*4 + r + 15 - c]
+      const f16* t1p = T1 + g * 4 * (LTW + 1) + 63 - 16 * w - c;
+      const f16* t2p = T2 + (w * 16 + c) * LTW + g * 4 + 15 - c;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s = sacc[nt][r] + (float)t1p[nt * 16 * LTW + r * (LTW + 1)] + (float)t2p[nt * 16 + r];
+          p[nt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s, k2, -rlse[nt * 16 + g * 4 + r]));
+        }
+    } else {
+      // the sub-window offsets are clamped here (one v_med3 each): padding queries must give an exact P = 0 (finite or
+      // -inf score, lse = +inf), not garbage, because their dS rows are stored
       const int16_t* ib = idx + (i0 + g * 4 - j + tq);
-      const f16* t1g = T1 + g * 4 * LT;
-      const f16* t2row = T2w + c * LT;
+      int sb2 = r_lo;  // first table row of this wave's T2 rows
+#pragma unroll
+      for (int x = 0; x < 4; ++x) sb2 = (w == x) ? r_lo + 16 * t0k[x] : sb2;
+      const f16* t1g = T1 + g * 4 * LTW;
+      const f16* t2row = T2 + (w * 16 + c) * LTW;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
+        const int sb1 = r_lo + 16 * t0q[nt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int wi = ib[nt * 16 + r];
-          const int w1 = clampi(wi - base1[nt], 0, 79), w2 = clampi(wi - base2, 0, 79);
-          const float s = sacc[nt][r] + (float)t1g[(nt * 16 + r) * LT + w1] + (float)t2row[w2];
+          const int w1 = clampi(wi - sb1, 0, 95), w2 = clampi(wi - sb2, 0, 95);
+          const float s = sacc[nt][r] + (float)t1g[(nt * 16 + r) * LTW + w1] + (float)t2row[w2];
           p[nt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s, k2, -rlse[nt * 16 + g * 4 + r]));
         }
       }
     }
-    if (it + 1 < nqt) load_win(it + 1, R);
     // ---- dP = dO.V^T, dS = P*(dP - D)*scale; packed to bf16 at once (dsb: dS, pfh: dropped-out P for the dV MFMA)
     bf16x4 dsb[4], pfh[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, g), vf[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(smem + A_DOS, nt * 16 + c, 4 + g), vf[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + A_DOS + nt * 2048 + fb0), vf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + A_DOS + nt * 2048 + fb1), vf[1], acc, 0, 0, 0);
       float keep[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f) {
 #pragma unroll
@@ -257,13 +319,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(BwdAArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         // dO^T fragment (row d = dt*16 + c, queries kk*32 + g*4 + {0..3} and +16) read transposed out of the swizzled
         // row-major dO tile that already feeds the dP MFMAs: lane (g, c) hands in 4 contiguous d of query row r
-        const int r = kk * 32 + g * 4 + (c >> 2);
+        const int r = g * 4 + (c >> 2);
         const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        const char* db = smem + A_DOS + r * 128 + ((ch ^ (r & 7)) << 4) + sub;
         union { tr16x4 h[2]; bf16x8 v; } u;
-        u.h[0] = lds_tr16((const bf16*)(smem + A_DOS + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
-        u.h[1] = lds_tr16((const bf16*)(smem + A_DOS + (r + 16) * 128 + ((ch ^ ((r + 16) & 7)) << 4) + sub));
-        const bf16x8 af = u.v;
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, dv[dt], 0, 0, 0);
+        u.h[0] = lds_tr16((const bf16*)(db + kk * 4096));
+        u.h[1] = lds_tr16((const bf16*)(db + kk * 4096 + 2048));
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, dv[dt], 0, 0, 0);
       }
     }
     // ---- (5) dS and dS^T leave through LDS transposes (T1 / T2 regions): 16-byte rows
@@ -298,6 +360,7 @@ struct ShearArgs {
   const bf16* PT;                         // transposed position table [nh][64][span2]
   const int16_t* relidx;
   const int32_t* klen;
+  const int32_t* border;
   bf16* out; long ldout;                  // row-major, head h at col h*64
   bf16* GT;                               // [nh][B][Sp/32][rcnt][32]
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
@@ -305,7 +368,7 @@ struct ShearArgs {
   int lin;                                // |delta| < lin: idx(delta) is injective (identity buckets) -> plain stores
 };
 constexpr int C_IDX = 0;           // int16[1024]: relative-index table padded to the tile grid
-constexpr int C_G = C_IDX + 2048;  // [32][Wg + 4] fp32
+constexpr int C_G = C_IDX + 2048;  // [32][Wg + 8] bf16
 
 // 2 waves x 16 rows; after the initial barrier (cooperative zeroing of G, index table) the waves never synchronise:
 //  * the transposed-operand fragments come straight from global memory (L2-resident: every row tile of a (batch, head)
@@ -322,20 +385,21 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int S = a.S, Sp = a.Sp, hi = 2 * S - 2;
-  const int LDG = a.Wg + 4;
+  const WgCoord wc = wg_coord(Sp / 32, a.nh, a.B, a.border);
+  const int bx = wc.x, r0 = bx * 32, h = wc.h, b = wc.b;
+  const int LDG = a.Wg + 8;  // bf16 elements; rows stay 16-byte aligned, 8 padding slots per row
   const int rl = w * 16 + c;  // local row
   const int row = r0 + rl;
-  float* G = (float*)(smem + C_G);
+  bf16* G = (bf16*)(smem + C_G);
   int16_t* idx = (int16_t*)(smem + C_IDX);
-  bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + blockIdx.x) * a.rcnt) * 32;
+  bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + bx) * a.rcnt) * 32;
   const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int kl = a.klen ? min(a.klen[b], S) : S;
   if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
     // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
     // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
-    if ((blockIdx.x & 1) && (r0 - 32 < kl))
+    if ((bx & 1) && (r0 - 32 < kl))
       for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
     if (row < S) {
       bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
@@ -353,9 +417,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int nks = min((rtop - rbase + 32) / 32, a.Wg / 32);
   const int izero = (int)a.relidx[S - 1];  // idx(0)
   {
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int vpr = nks * 8;  // 16-byte vectors per row
-    for (int t = tid; t < 32 * vpr; t += 128) *(f32x4*)(G + (t / vpr) * LDG + (t % vpr) * 4) = z4;
+    const int vpr = nks * 4;  // 16-byte vectors per row
+    for (int t = tid; t < 32 * vpr; t += 128) *(bf16x8*)(G + (t / vpr) * LDG + (t % vpr) * 8) = z8;
   }
   attn::load_idx_padded(idx, a.relidx, S, Sp, tid, 128);
   // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here
@@ -372,9 +435,9 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int nct = (kl + 63) / 64;
   const bf16* ytb = a.YT + h * a.y_sh + b * a.y_sb + (long)c * a.y_sd + g * 8;
   const int16_t* ib = idx + (NEG ? (Sp - 1 - row + g * 8) : (Sp - 1 + row - g * 8));  // idx(delta) = ib[+-(col - g*8)]
-  float* grow = G + rl * LDG - rbase;  // indexed by the absolute table row
+  bf16* grow = G + rl * LDG - rbase;  // indexed by the absolute table row
   const int wmax = rbase + nks * 32 - 1;
-  const int dummy = rbase + a.Wg;      // the row's 4 padding floats: never read
+  const int dummy = rbase + a.Wg;      // the row's padding slots: never read
   // lane-linear part of the identity-band slot: slot = izero + delta, delta = +-(row - col)
   const int lin0 = izero + (NEG ? (g * 8 - row) : (row - g * 8));
   const int rw = r0 + w * 16;
@@ -403,9 +466,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
         const int s0 = NEG ? (lin0 + cb) : (lin0 - cb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float x = bf2f(xv[e]);
           const int slot = NEG ? (s0 + e) : (s0 - e);
-          grow[x != 0.f ? slot : dummy] = x;  // injective inside the band and G starts at 0: a plain store is exact
+          grow[bf2f(xv[e]) != 0.f ? slot : dummy] = xv[e];  // injective inside the band and G starts at 0: a plain store is exact
         }
       } else {
 #pragma unroll
@@ -414,9 +476,16 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
           if (x != 0.f) {
             const int dlt = NEG ? (cb + g * 8 + e - row) : (row - cb - g * 8 - e);
             const int gi = clampi((int)(NEG ? ib[cb + e] : ib[-(cb + e)]), rbase, wmax);
-            // LDS fp32 atomics (~190 cycles per wave instruction) only where log buckets can collide
-            if (abs(dlt) < a.lin) grow[gi] = x;
-            else atomicAdd(&grow[gi], x);
+            // LDS atomics (packed bf16 add on the element's aligned pair, the other half adds 0) only where log buckets
+            // can collide; a bucket collects a handful of terms, each partial sum rounded to bf16 like G itself is
+            // before it meets the matrix cores
+            if (abs(dlt) < a.lin) {
+              grow[gi] = xv[e];
+            } else {
+              bf16x2 pv = {(bf16)0.f, (bf16)0.f};
+              pv[gi & 1] = xv[e];
+              __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) bf16x2*)(grow + (gi & ~1)), pv);
+            }
           }
         }
       }
@@ -449,15 +518,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     }
   };
   auto table_step = [&](int kk, const bf16x8* af) {
-    const float* gp = G + rl * LDG + kk * 32 + g * 8;
-    const f32x4 g0 = *(const f32x4*)gp;
-    const f32x4 g1 = *(const f32x4*)(gp + 4);
-    bf16x8 bfv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bfv[e] = f2bf(g0[e]);
-      bfv[4 + e] = f2bf(g1[e]);
-    }
+    const bf16x8 bfv = *(const bf16x8*)(G + rl * LDG + kk * 32 + g * 8);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfv, acc[dt], 0, 0, 0);
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
@@ -501,28 +562,31 @@ extern "C" int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float*
 extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO,
                                       int64_t ldo,
                                       const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
-                                      const int32_t* mask, const int32_t* klen, const float* lse, const float* Dv, float scale, float p_drop,
+                                      const int32_t* mask, const int32_t* klen, const int32_t* border, const float* lse, const float* Dv, float scale, float p_drop,
                                       uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
-                                      int nh, int span2, void* stream) {
+                                      int nh, int span2, int lin_span, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
+  if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
-  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
-             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2};
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A_TOTAL);
+  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
+             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span};
+  attn_debug_init();
+  const int smem_bytes = a_total(Sp);
+  static int attr_bytes = 0;
+  if (smem_bytes > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_bytes = smem_bytes;
   }
-  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(Sp / 64, nh, B), dim3(256), A_TOTAL, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3((unsigned)(Sp / 64) * nh * B), dim3(256), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
-                                         int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen, void* out,
-                                         int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
+                                         int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen,
+                                         const int32_t* border, void* out, int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
                                          int Sp, int nh, int span2, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
@@ -532,9 +596,10 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   if (Wg > span2) Wg = span2;
   Wg = (Wg + 31) / 32 * 32;
   if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
-  ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, (bf16*)out, ldout, (bf16*)GT,
+  ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, border, (bf16*)out, ldout, (bf16*)GT,
               B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span};
-  const int smem_bytes = C_G + 32 * (Wg + 4) * 4;
+  attn_debug_init();
+  const int smem_bytes = C_G + 32 * (Wg + 8) * 2;
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
@@ -543,7 +608,7 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
     if (e2 != hipSuccess) return (int)e2;
     attr_bytes = smem_bytes;
   }
-  dim3 grid(Sp / 32, nh, B);
+  dim3 grid((unsigned)(Sp / 32) * nh * B);
   if (neg)
     hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   else

@@ -32,6 +32,47 @@ __device__ __forceinline__ f16x4 to_f16x4(f32x4 v) {
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// Workgroup -> (tile x, head h, sample b) for a 1-D grid of nx * nh * B workgroups.
+//  * the nx tiles of one (sample, head) share their K/V (or Q/dO, or transposed-operand) rows: they are placed on ONE XCD
+//    (the dispatcher hands block L to XCD L % 8 -- observed, used for L2 affinity only) and dispatched back to back, so
+//    those rows are fetched into one L2 once instead of into up to nx of them;
+//  * samples are walked in the caller's `border` order (longest first): the work per sample grows with klen^2 and the
+//    grid is several waves deep, so the long samples must not be the last ones dispatched.
+struct WgCoord { int x, h, b; };
+#ifdef FBL_DEBUG_SWITCHES
+__device__ int g_attn_plainmap;  // measurement switch (debug builds only): 1 = plain b-major mapping
+#define FBL_ATTN_PLAINMAP g_attn_plainmap
+static inline void attn_debug_init() {
+  static bool once = false;
+  if (!once) {
+    const int v = FBL_ENV_INT("FBL_ATTN_PLAINMAP", 0);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_plainmap), &v, sizeof(v));
+    once = true;
+  }
+}
+#else
+#define FBL_ATTN_PLAINMAP 0
+static inline void attn_debug_init() {}
+#endif
+__device__ __forceinline__ WgCoord wg_coord(int nx, int nh, int B, const int32_t* border) {
+  const int L = blockIdx.x, ng = nh * B;
+  int G, x;
+  if ((ng & 7) == 0 && !FBL_ATTN_PLAINMAP) {
+    const int s = L >> 3;
+    G = (s / nx) * 8 + (L & 7);
+    x = s % nx;
+  } else {
+    G = L / nx;
+    x = L % nx;
+  }
+  const int bs = G / nh;
+  WgCoord c;
+  c.x = x;
+  c.h = G - bs * nh;
+  c.b = border ? border[bs] : bs;
+  return c;
+}
+
 // ds_read_b64_tr_b16: the 16 lanes of a group each pass the address of 4 contiguous 16-bit elements -- together a
 // [4 rows][16 columns] block of a row-major LDS image (lane i: row i/4, columns (i%4)*4..+3) -- and lane i receives
 // column i of that block, i.e. 4 consecutive rows of one column (lane mapping probed in tools/probe/tr16_probe.hip).

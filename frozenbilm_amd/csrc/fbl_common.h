@@ -12,6 +12,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define FBL_WAVE 64
 
+// Experiment switches (tile-shape overrides, ablations) exist only in builds made with -DFBL_DEBUG_SWITCHES
+// (FBL_DEBUG_BUILD=1 python -m frozenbilm_amd.build): the product library reads no environment variable.
+#ifdef FBL_DEBUG_SWITCHES
+#include <stdlib.h>
+#define FBL_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define FBL_ENV_INT(name, dflt) (dflt)
+#endif
+
 #define FBL_CHECK_LAUNCH()                                     \
   do {                                                         \
     hipError_t e__ = hipGetLastError();                        \

@@ -414,7 +414,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
   g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
   if (seg_n > 0) {
-    if ((seg_n & 3) || seg_n >= N || !seg_out || accumulate || batch != 1) return FBL_ERR_ARG;
+    // The epilogue branches per LANE on "column >= seg_n" but stages accumulators through per-WAVE LDS patches that all 64
+    // lanes fill: the segment boundary must not cut a wave's column range.  A wave of the 2-stage kernels owns 64
+    // contiguous columns, a wave of the 256-wide tiles (2-stage and 8-phase) two 32-column ranges 128 apart -> the
+    // boundary has to be a multiple of 64, and of 256 for the wide tiles (otherwise the narrow tiles take the problem).
+    if ((seg_n & 63) || seg_n >= N || !seg_out || accumulate || batch != 1) return FBL_ERR_ARG;
     g.drop_ld = seg_ld;
   }
   if (p_drop > 0.f) {
@@ -424,16 +428,17 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
-  static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
-  const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0) && big_tile_shape(M, N, batch);
+  static const int force_small = FBL_ENV_INT("FBL_GEMM_SMALL", 0);
+  const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0) && (seg_n <= 0 || (seg_n & 255) == 0) &&
+                   big_tile_shape(M, N, batch);
   // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
   // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
   // the CUs the last round does not need start up to 0.4 tiles late, which costs no wall time and takes the CUs out of
   // lockstep (measured [9024,4608,1536]: 146 -> 133 us).  With a nearly empty last round (FFN-up: 816 tiles, 48 left) the
   // split stays better: an epilogue costs a CU 10-20 us of VALU / store time that nothing on that CU overlaps, so a
   // fourth round of full tiles (222 us) loses to three rounds plus small tiles (208 us).  FBL_GEMM8_SKEW=0 disables.
-  static const int skew_mode = getenv("FBL_GEMM8_SKEW") ? atoi(getenv("FBL_GEMM8_SKEW")) : 50;
-  static const int gemm8_on = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
+  static const int skew_mode = FBL_ENV_INT("FBL_GEMM8_SKEW", 50);
+  static const int gemm8_on = FBL_ENV_INT("FBL_GEMM8", 3);
   bool skewed_single_launch = false;
   if (big && splitk_ws_floats >= 0 && skew_mode > 0 && gemm8_on > 0 && gemm8_eligible(g)) {
     const long total = (long)((N + 255) / 256) * ((M + 255) / 256);
@@ -469,7 +474,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
         // -- the chip leaves lockstep (the epilogue of a round is an HBM burst: every CU stores its tile at the same moment
         // while the memory system idles during the main loops) and the remainder costs no round of its own.
         // bit 1: remainder in 64x128 tiles (320 rows x 6144: 240 workgroups instead of 144).
-        static const int rem_mode = getenv("FBL_GEMM_REM") ? atoi(getenv("FBL_GEMM_REM")) : 3;
+        static const int rem_mode = FBL_ENV_INT("FBL_GEMM_REM", 3);
         static hipStream_t rem_stream = nullptr;
         static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         bool forked = false;
@@ -511,7 +516,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   // 224x256 tiles when they cover the problem in fewer (rounds x tile area) than 256x256 -- the N = 1536 GEMMs of the
   // step: 38 x 6 = 228 tiles in one round instead of 204 tiles that are 14 % bigger
   bool use_224 = false;
-  static const int no224 = getenv("FBL_GEMM_NO224") ? atoi(getenv("FBL_GEMM_NO224")) : 0;
+  static const int no224 = FBL_ENV_INT("FBL_GEMM_NO224", 0);
   if (use_big && splitk_ws_floats >= 0 && !no224) {
     int dev = 0, n_cu = 256;
     static int cu_cached = 0;
@@ -528,7 +533,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   }
   // 64x128 tiles for tall, narrow problems whose 128x128 grid covers less than the chip (the adapter bottleneck
   // projections: 8512 x 192 -> 134 workgroups): twice the workgroups, so twice the CUs pull operands from L2
-  static const int no64 = getenv("FBL_GEMM_NO64") ? atoi(getenv("FBL_GEMM_NO64")) : 0;
+  static const int no64 = FBL_ENV_INT("FBL_GEMM_NO64", 0);
   const bool use_64 = !use_big && !accumulate && !no64 && batch == 1 &&
                       ((M >= 2048 && splitk_ws_floats >= 0) || splitk_ws_floats == -3) &&
                       (long)((M + 127) / 128) * ((N + 127) / 128) < 200;
@@ -539,7 +544,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   // FBL_GEMM8=0 switches it off, 1 keeps the 224x256 shapes on the 2-stage kernel, 2 runs them as 256x256 8-phase tiles
   // (measured: [8512,1536,6144] 915 -> 1139 TFLOP/s although only 204 of 256 CUs get a tile), 3 (default) as 224x256
   // 8-phase tiles (228 tiles).
-  static const int gemm8_mode = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
+  static const int gemm8_mode = FBL_ENV_INT("FBL_GEMM8", 3);
   if (use_big && gemm8_mode > 0 && (!use_224 || gemm8_mode >= 2) && gemm8_eligible(g)) {
     GemmArgs g8 = g;
     const bool r224 = use_224 && gemm8_mode >= 3;
@@ -563,7 +568,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, dim3(NW_ * 64), smem_bytes, (hipStream_t)stream, g);                         \
   } while (0)
-  static const int deep64 = getenv("FBL_GEMM_DEEP") ? atoi(getenv("FBL_GEMM_DEEP")) : 1;
+  static const int deep64 = FBL_ENV_INT("FBL_GEMM_DEEP", 1);
 #define FBL_GEMM_LAUNCH_DEEP(ACT_, AUX_)                                                                        \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \
@@ -597,7 +602,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, dim3(512), smem_bytes, (hipStream_t)stream, g);                              \
   } while (0)
-  static const int exp_sched = getenv("FBL_GEMM_SCHED") ? atoi(getenv("FBL_GEMM_SCHED")) : 0;
+  static const int exp_sched = FBL_ENV_INT("FBL_GEMM_SCHED", 0);
   if (use_big && exp_sched > 0 && act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) {  // experiment switch (plain epilogue)
     if (exp_sched == 1) FBL_GEMM_LAUNCH_SCHED(1);
     else if (exp_sched == 2) FBL_GEMM_LAUNCH_SCHED(2);
@@ -642,8 +647,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
 // Host-side query (no launch): which kernel fbl_gemm_bf16_nt gives a plain launch of this shape to -- 8: the 8-phase
 // kernel of gemm8.hip (whole rounds; a remainder of rows may go to 64x128 tiles of the 2-stage kernel), 2: the 2-stage kernel.
 extern "C" int fbl_gemm_plan(int M, int N, int K, int batch, int splitk) {
-  static const int force_small = getenv("FBL_GEMM_SMALL") ? atoi(getenv("FBL_GEMM_SMALL")) : 0;
-  static const int gemm8_on = getenv("FBL_GEMM8") ? atoi(getenv("FBL_GEMM8")) : 3;
+  static const int force_small = FBL_ENV_INT("FBL_GEMM_SMALL", 0);
+  static const int gemm8_on = FBL_ENV_INT("FBL_GEMM8", 3);
   if (force_small || gemm8_on <= 0 || splitk > 1 || !big_tile_shape(M, N, batch)) return 2;
   GemmArgs g{};
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.splitk = 1;
@@ -676,11 +681,12 @@ extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void*
 // composed with the dense weight, rebuilt by the caller whenever Wd changes) and bm = [b ; Wd.b + bd],
 //     [ y | z_pre ] = x . Wm^T + bm,     C = y (fp32 and/or bf16, N1 columns),     z = dropout_p(relu(z_pre)) (bf16, A columns).
 // The bottleneck activations come out of the epilogue of the tile column(s) beyond N1 -- no separate K = N1 GEMM that
-// re-reads y, no launch.  Dropout keys as in fbl_adapter_down_fwd: (seed, m*ldz + a).  N1 % 4 == 0.
+// re-reads y, no launch.  Dropout keys as in fbl_adapter_down_fwd: (seed, m*ldz + a).  N1 % 64 == 0 (a wave's column range
+// must not straddle the segment boundary); the 256-wide tiles additionally need N1 % 256 == 0 and are not used otherwise.
 extern "C" int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1,
                                           int A, int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy,
                                           float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream) {
-  if (A <= 0 || (N1 & 3)) return FBL_ERR_ARG;
+  if (A <= 0 || (N1 & 63)) return FBL_ERR_ARG;
   return gemm_nt_impl(x_bf16, ldx, wm_bf16, ldw, M, N1 + A, K, bias_m, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_NONE, nullptr, 0,
                       y_f32, y_bf16, nullptr, ldy, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, N1,
                       z_bf16, ldz);

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 
 template <int ACT, int AUX, bool R224>
 int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-  static const int var = getenv("FBL_GEMM8_VAR") ? atoi(getenv("FBL_GEMM8_VAR")) : 3;
+  static const int var = FBL_ENV_INT("FBL_GEMM8_VAR", 3);
 #define FBL_G8_LAUNCH(VAR_)                                                                                     \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \

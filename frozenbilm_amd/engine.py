@@ -61,6 +61,8 @@ class Engine:
         self.nh = cfg.num_attention_heads
         self.nL = cfg.num_hidden_layers
         self.span2 = 2 * cfg.att_span
+        # |i - j| < lin_span: identity buckets of the relative-position map (model/deberta.py:578-589: mid = bucket_size // 2)
+        self.lin_span = min(cfg.position_buckets // 2, cfg.att_span) if cfg.position_buckets > 0 else 0
         self.F = model.features_dim
         self.Fp = _ru(self.F, 64) if self.F else 0
         self.A1 = self.H // model.ds_factor_attn if model.ds_factor_attn else 0
@@ -507,7 +509,7 @@ class Engine:
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
         L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], qkv[:N, 2 * H:], pk, pq, self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
-                          seed=sv.seed_att, klen=run.klen)
+                          seed=sv.seed_att, klen=run.klen, border=run.border, lin=self.lin_span)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
         ad = self.ad[li]
         y1, ob, z1, sv.seed_ad1 = self._dense_adapter(run, li, ctx, W, "Wo", "bo", ad.get("a1"), self.A1, self.merge1, N)
@@ -536,6 +538,8 @@ class Engine:
         run.mask_i32 = run.mask
         pos1 = torch.arange(1, S + 1, device=dev, dtype=torch.int32)
         run.klen = (run.mask.view(B, S) * pos1).amax(1).to(torch.int32).contiguous()  # last valid position + 1
+        # attention work per sample grows with klen^2: the attention kernels dispatch the samples longest first
+        run.border = torch.argsort(run.klen, descending=True, stable=True).to(torch.int32).contiguous()
         mask_f = run.mask.to(F32)
         run.mask_f = mask_f
         # ---- embeddings (model/deberta.py:997-1058): cat(linear_video(video), E[ids]) -> LN -> *mask -> dropout

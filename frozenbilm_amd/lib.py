@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfbl.so")
+# FBL_LIB: measurement tools point this at libfbl_dbg.so (FBL_DEBUG_BUILD=1 build); the product never sets it
+LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
@@ -45,12 +46,12 @@ SIGNATURES = {
     "fbl_colsum_ws_floats": (_l, [_i]),
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
-    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
-                                 _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
+                                 _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
-                                    _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+    "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -348,7 +349,8 @@ def head_transpose(v, vt, B, S, Sp, nh, head_major=False):
     _chk(load().fbl_head_transpose(_p(v), ldv, _p(vt), B, S, Sp, nh, sh, sb, sd, _stream()), "fbl_head_transpose")
 
 
-def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0, klen=None):
+def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0, klen=None,
+                    border=None, lin=0):
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (pk, "pk"), (pq, "pq"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
@@ -356,8 +358,8 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     ldq, ldk, ldv, ldp, ldo = _rows2d(q, "q"), _rows2d(k, "k"), _rows2d(v, "v"), _rows2d(pk, "pk"), _rows2d(ctx, "ctx")
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
-                                    _p(mask), _p(klen), float(scale), float(p_drop), int(seed), _p(ctx), ldo, _p(lse), B,
-                                    S, Sp, nh, span2, _stream()), "fbl_disent_attn_fwd")
+                                    _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _p(ctx), ldo,
+                                    _p(lse), B, S, Sp, nh, span2, int(lin), _stream()), "fbl_disent_attn_fwd")
 
 
 def attn_rowdot(dO, O, out, B, S, nh):
@@ -367,22 +369,22 @@ def attn_rowdot(dO, O, out, B, S, nh):
 
 
 def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
-                       p_drop=0.0, seed=0, klen=None):
+                       p_drop=0.0, seed=0, klen=None, border=None, lin=0):
     ldq = _rows2d(q, "q")
     assert _rows2d(k, "k") == ldq and _rows2d(v, "v") == ldq
     ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(pk), _p(pq), ldp,
-                                       _p(relidx), _p(mask), _p(klen), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
-                                       _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, _stream()),
+                                       _p(relidx), _p(mask), _p(klen), _p(border), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
+                                       _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, int(lin), _stream()),
          "fbl_disent_attn_bwd_ds")
 
 
 def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None,
-                          rmin=0, rcnt=None, lin=0):
+                          rmin=0, rcnt=None, lin=0, border=None):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
-    _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(out), ldout,
+    _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(border), _p(out), ldout,
                                           _p(GT), rmin, span2 if rcnt is None else rcnt, int(lin), B, S, Sp, nh, span2, _stream()),
          "fbl_disent_attn_bwd_shear")
 

@@ -76,7 +76,8 @@ int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, i
  * fbl_gemm_bf16_nt, whenever Wd changes), bias_m = [b ; Wd.b + bd] ([N1 + A] fp32):
  *   y[M, N1] = x.W^T + b  -> y_f32 and/or y_bf16 (row stride ldy);   z[M, A] = dropout_p(relu(x.(Wd.W)^T + Wd.b + bd)) -> z_bf16.
  * z equals fbl_adapter_down_fwd(y) up to bf16 rounding of the operands (y is not rounded to bf16 on the way), dropout
- * keyed by (seed, m*ldz + a).  N1 % 4 == 0, K % 64 == 0, ldx/ldw % 8 == 0.
+ * keyed by (seed, m*ldz + a).  N1 % 64 == 0 (FBL_ERR_ARG otherwise: the segment boundary must not cut a wave's column
+ * range; the 256-wide tiles are only used when N1 % 256 == 0), K % 64 == 0, ldx/ldw % 8 == 0.
  * ref: model/deberta.py:255-257, 329-331 (dense -> adapter) + model/adapter.py:38-41. */
 int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1, int A,
                                int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
@@ -181,12 +182,17 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
  *   MFMA fragments come from ds_read_b64_tr_b16;
  *   pk/pq bf16 [2*span, ldp]; relidx int16 [2S-1]: relidx[d+S-1] = clamp(bucket(d)+span, 0, 2span-1);
  *   mask int32 [B,S]; klen int32 [B] (optional): last valid position + 1 -- tiles beyond it are exactly zero and are
- *   skipped; out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
+ *   skipped; border int32 [B] (optional): a permutation of the samples, the order in which they are dispatched
+ *   (longest first balances the ragged batch over the CUs; the results do not depend on it);
+ *   lin_span: |d| < lin_span => relidx[d+S-1] = relidx[S-1] + d (the identity buckets: position_buckets/2; 0 if
+ *   unknown) -- tile pairs inside that band take index-table-free addressing;
+ *   out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
 int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                         const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
-                        const int32_t* mask, const int32_t* klen, float scale, float p_drop, uint64_t seed, void* ctx,
-                        int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2, void* stream);
+                        const int32_t* mask, const int32_t* klen, const int32_t* border, float scale, float p_drop,
+                        uint64_t seed, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
+                        int lin_span, void* stream);
 
 /* Backward of fbl_disent_attn_fwd, three launches (ref: autograd of model/deberta.py:717-947, XSoftmax.backward
  * :134-138, XDropout.backward :185-190):
@@ -207,12 +213,13 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
-                           const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen, const float* lse,
-                           const float* Dv,
+                           const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen,
+                           const int32_t* border, const float* lse, const float* Dv,
                            float scale, float p_drop, uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B,
-                           int S, int Sp, int nh, int span2, void* stream);
+                           int S, int Sp, int nh, int span2, int lin_span, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
-                              const void* PT, const int16_t* relidx, const int32_t* klen, void* out, int64_t ldout,
+                              const void* PT, const int16_t* relidx, const int32_t* klen, const int32_t* border,
+                              void* out, int64_t ldout,
                               void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
                               int span2, void* stream);
 

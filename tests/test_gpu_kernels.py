@@ -472,17 +472,23 @@ def _klen(mask):
     return (mask * torch.arange(1, S + 1, device=mask.device, dtype=torch.int32)).amax(1).to(torch.int32).contiguous()
 
 
-def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None):
+def _border(klen):
+    return torch.argsort(klen, descending=True, stable=True).to(torch.int32).contiguous()
+
+
+def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None, border=None, lin=128):
     H = nh * 64
     Sp = (S + 63) // 64 * 64
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.empty(B, nh, S, device=DEV)
     L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx,
-                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen)
+                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen, border=border, lin=lin)
     return ctx, lse
 
 
-@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 64, 1), (3, 129, 2), (2, 266, 3), (1, 512, 2)])
+# nh * B a multiple of 8 takes the XCD-aware workgroup mapping, everything else the plain one
+@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 64, 1), (3, 129, 2), (2, 266, 3), (1, 512, 2), (4, 150, 2),
+                                    (8, 266, 3)])
 def test_attention_fwd(L, B, S, nh):
     qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=10 + S)
     ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh)
@@ -503,6 +509,12 @@ def test_attention_fwd(L, B, S, nh):
     c_full, l_full = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh)
     c_skip, l_skip = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh, klen=_klen(mask2))
     assert torch.equal(c_full, c_skip) and torch.equal(l_full, l_skip)
+    # the dispatch order of the samples (longest first) changes nothing
+    c_ord, l_ord = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh, klen=_klen(mask2), border=_border(_klen(mask2)))
+    assert torch.equal(c_full, c_ord) and torch.equal(l_full, l_ord)
+    # index-table-free addressing inside the identity band (lin = position_buckets / 2) gathers the very same values
+    c_tab, l_tab = _run_attn_fwd(L, qkv, pqk, mask2, relidx, B, S, nh, lin=0)
+    assert torch.equal(c_full, c_tab) and torch.equal(l_full, l_tab)
 
 
 def test_attention_fwd_dropout_rate(L):
@@ -518,12 +530,12 @@ def test_attention_fwd_dropout_rate(L):
     assert ctx.float().std().item() > 1e-3  # not all ones: dropout really dropped something
 
 
-@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1)])
+@pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1), (4, 200, 2)])
 def test_attention_bwd(L, B, S, nh):
     from frozenbilm_amd.attn_bwd import disent_attn_bwd
 
     qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=20 + S)
-    if B == 3:  # short samples: whole 64-row steps of G^T beyond klen stay unwritten and must be skipped downstream
+    if B >= 3:  # short samples: whole 64-row steps of G^T beyond klen stay unwritten and must be skipped downstream
         mask[1, 70:] = 0
         mask[2, 33:] = 0
     if S == 512:
@@ -551,6 +563,7 @@ def test_attention_bwd(L, B, S, nh):
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
     run.klen = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
+    run.border = _border(run.klen) if (run.klen is not None and B >= 3) else None  # longest-first dispatch (XCD-aware map at B=4)
     import frozenbilm_amd.attn_bwd as AB
     AB.POISON_GT = True  # unwritten G^T blocks hold NaN: the position-table GEMMs must skip exactly those
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 0
@@ -700,8 +713,11 @@ def test_mask_tokens_device(L):
     assert not torch.equal(l3.cpu(), labels)
 
 
-@pytest.mark.parametrize("M,N1,A,K", [(300, 128, 16, 128), (4100, 1536, 192, 256), (8512, 1536, 192, 1536), (1000, 768, 96, 3072)])
-# small tiles; 8-phase 256x256 tiles (7th tile column = the bottleneck); the Wo shape of the step; a mid-size one
+@pytest.mark.parametrize("M,N1,A,K", [(300, 128, 16, 128), (4100, 1536, 192, 256), (8512, 1536, 192, 1536), (1000, 768, 96, 3072),
+                                      (2500, 192, 24, 128), (4100, 1152, 144, 256)])
+# small tiles; 8-phase 256x256 tiles (7th tile column = the bottleneck); the Wo shape of the step; a mid-size one;
+# N1 = 192 (a multiple of 64 only); N1 = 1152 = 4.5 x 256: big-tile shape whose boundary would cut a wave's two 32-column
+# ranges -> must run on the narrow tiles
 def test_dense_adapter_down_merged(L, M, N1, A, K):
     """fbl_dense_adapter_down_fwd: y = x.W^T + b and z = dropout(relu(y.Wd^T + bd)) from ONE GEMM against [W ; Wd.W]."""
     x = bf(rnd(M, K, seed=1)).to(BF16)
@@ -733,4 +749,7 @@ def test_dense_adapter_down_merged(L, M, N1, A, K):
     keep = ones.float() > 0
     assert abs(keep.float().mean().item() - (1 - p)) < 0.02
     assert (z2.float()[~keep] == 0).all()
+    if N1 == 128:  # the contract: a segment boundary that is not a multiple of 64 is refused, not silently mis-staged
+        with pytest.raises(RuntimeError):
+            L.dense_adapter_down_fwd(x[:, :K], Wm[: 100 + A], bm[: 100 + A].contiguous(), 100, z, y_f32=y32[:, :100].contiguous())
     close(z2.float()[keep], z.float()[keep] / (1 - p), 2e-2, 1e-2, "kept values")
