@@ -1,6 +1,6 @@
 """Host-side orchestration of the disentangled-attention backward (see csrc/attn_bwd.hip for the math).
 
-    dO --rowdot--> D            K,Q,dO --head_transpose--> K^T, Q^T, dO^T (head-major [nh,64,B,Sp])
+    dO --rowdot--> D            K,Q --head_transpose--> K^T, Q^T (head-major [nh,64,B,Sp])
     kernel A : dV, dS, dS^T
     shear(0) : dQ = dS.K   + G1.PK   (+ G1^T)        shear(1) : dK = dS^T.Q + G2.PQ   (+ G2^T)
     GEMM     : dPK[h] = G1^T[h] . Q^T[h]^T           GEMM     : dPQ[h] = G2^T[h] . K^T[h]^T     (split-K, per head)
@@ -33,6 +33,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     border = getattr(run, "border", None)
     scale = 1.0 / math.sqrt(64 * 3)
 
+    # (folding D_i = dO_i . O_i into kernel A was measured: +43 us there for the O tiles on its critical path vs 8 us here)
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
     L.attn_rowdot(dctx, sv.ctx, Dv, B, S, nh)
     KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)

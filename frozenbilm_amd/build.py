@@ -60,7 +60,7 @@ def _compile(src: str, force: bool) -> str:
             name = line.split("Function Name:")[1].split("[")[0].strip()
         elif "ScratchSize [bytes/lane]:" in line:
             n = int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
-            if n > 64:  # (a handful of spilled registers outside the inner loop is tolerated and only reported)
+            if n > 64:  # (a handful of spilled loop-invariant registers -- addresses -- is tolerated and only reported)
                 bad.append(f"{name}: {n} bytes/lane")
             elif n > 0:
                 print(f"[frozenbilm_amd.build] note: {name} spills {n} bytes/lane")

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
     // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
     if ((bx & 1) && (r0 - 32 < kl))
-      for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
+      if (!(FBL_ATTN_DBGBITS & 64)) for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
     if (row < S) {
       bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here
   for (int id = tid; id < a.rcnt * 4; id += 128) {
     const int r = a.rmin + (id >> 2);
-    if (r < rbase || r >= rbase + nks * 32) *(bf16x8*)(gt + (long)id * 8) = z8;
+    if (!(FBL_ATTN_DBGBITS & 64) && (r < rbase || r >= rbase + nks * 32)) *(bf16x8*)(gt + (long)id * 8) = z8;
   }
   const long xbase = (((long)b * a.nh + h) * Sp + row) * Sp;
   f32x4 acc[4];
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I0, zf, 0, 0, 0);  // [row g*4+j][table row kk*32 + c]
     const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I1, zf, 0, 0, 0);  // [row g*4+j][table row kk*32+16+c]
     const int ra = rbase + kk * 32 + c - a.rmin, rb = ra + 16;
-    if (ra >= 0 && ra < a.rcnt)
+    if (ra >= 0 && ra < a.rcnt && !(FBL_ATTN_DBGBITS & 128))
       *(bf16x4*)(gt + (long)ra * 32 + w * 16 + g * 4) = (bf16x4){f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3])};
-    if (rb >= 0 && rb < a.rcnt)
+    if (rb >= 0 && rb < a.rcnt && !(FBL_ATTN_DBGBITS & 128))
       *(bf16x4*)(gt + (long)rb * 32 + w * 16 + g * 4) = (bf16x4){f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
   };
   bf16x8 pa[4], pb[4];

@@ -41,17 +41,22 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 struct WgCoord { int x, h, b; };
 #ifdef FBL_DEBUG_SWITCHES
 __device__ int g_attn_plainmap;  // measurement switch (debug builds only): 1 = plain b-major mapping
+__device__ int g_attn_dbgbits;   // FBL_ATTN_DBG (backward kernels: 64 = no zero fill of G^T, 128 = no G^T stores)
 #define FBL_ATTN_PLAINMAP g_attn_plainmap
+#define FBL_ATTN_DBGBITS g_attn_dbgbits
 static inline void attn_debug_init() {
   static bool once = false;
   if (!once) {
     const int v = FBL_ENV_INT("FBL_ATTN_PLAINMAP", 0);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_plainmap), &v, sizeof(v));
+    const int d = FBL_ENV_INT("FBL_ATTN_DBG", 0);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbgbits), &d, sizeof(d));
     once = true;
   }
 }
 #else
 #define FBL_ATTN_PLAINMAP 0
+#define FBL_ATTN_DBGBITS 0
 static inline void attn_debug_init() {}
 #endif
 __device__ __forceinline__ WgCoord wg_coord(int nx, int nh, int B, const int32_t* border) {

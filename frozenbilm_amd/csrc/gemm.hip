@@ -372,6 +372,32 @@ __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, 
 
 }  // namespace
 
+// Fork / join events of one (stream, aux_stream) pair.  The library owns no stream; the events are its only process
+// state: created on first use for the pair (on the device that is current in the calling thread, which must be the
+// streams' device), kept for the life of the process, looked up under a mutex.  One pair of events per pair of streams
+// is enough: a stream is fed by one thread at a time, and re-recording an event only affects waits issued afterwards.
+#include <map>
+#include <mutex>
+#include <utility>
+static bool fork_join_events(hipStream_t s, hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
+  static std::mutex mu;
+  static std::map<std::pair<hipStream_t, hipStream_t>, std::pair<hipEvent_t, hipEvent_t>> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pool.find({s, aux});
+  if (it == pool.end()) {
+    hipEvent_t f = nullptr, j = nullptr;
+    if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
+      (void)hipEventDestroy(f);
+      return false;
+    }
+    it = pool.emplace(std::make_pair(s, aux), std::make_pair(f, j)).first;
+  }
+  *fork = it->second.first;
+  *join = it->second.second;
+  return true;
+}
+
 // p_drop > 0 (ReLU epilogue only): dropout of the activated output, element (m, n) keyed by (drop_seed, m*ldc + n)
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                         const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
@@ -380,7 +406,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                         int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
                         float p_drop, uint64_t drop_seed, void* stream, int seg_n = 0, void* seg_out = nullptr,
-                        int64_t seg_ld = 0, int64_t drop_row0 = 0) {
+                        int64_t seg_ld = 0, int64_t drop_row0 = 0, void* aux_stream = nullptr) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
@@ -469,26 +495,22 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       const int tm_big = (int)((total - rem) / tn);             // whole rounds worth of M tiles
       const int m_big = tm_big * 256;
       if (tm_big >= 1 && m_big < M && M - m_big >= 64 && !splitk_ws) {
-        // FBL_GEMM_REM bit 0: the remainder rows run on a helper stream, launched BEFORE the big tiles (fork / join by
-        // events): its workgroups take their CUs first, so those CUs reach their first big tile a fraction of a tile late
-        // -- the chip leaves lockstep (the epilogue of a round is an HBM burst: every CU stores its tile at the same moment
-        // while the memory system idles during the main loops) and the remainder costs no round of its own.
-        // bit 1: remainder in 64x128 tiles (320 rows x 6144: 240 workgroups instead of 144).
+        // The remainder rows run on the CALLER's aux_stream (if one is given), launched BEFORE the big tiles and forked
+        // from / joined back into `stream` by events: its workgroups take their CUs first, so those CUs reach their first
+        // big tile a fraction of a tile late -- the chip leaves lockstep (the epilogue of a round is an HBM burst: every CU
+        // stores its tile at the same moment while the memory system idles during the main loops) and the remainder costs
+        // no round of its own.  Without an aux stream the remainder simply precedes the big tiles on `stream`.
+        // FBL_GEMM_REM (debug builds) bit 0: use the aux stream; bit 1: remainder in 64x128 tiles (320 rows x 6144: 240
+        // workgroups instead of 144).
         static const int rem_mode = FBL_ENV_INT("FBL_GEMM_REM", 3);
-        static hipStream_t rem_stream = nullptr;
-        static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         bool forked = false;
-        if ((rem_mode & 1) && !rem_stream) {
-          if (hipStreamCreateWithFlags(&rem_stream, hipStreamNonBlocking) != hipSuccess ||
-              hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-              hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-            return FBL_ERR_ARG;
-        }
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         void* s_rem = stream;
-        if (rem_mode & 1) {
+        if ((rem_mode & 1) && aux_stream && aux_stream != stream) {
+          if (!fork_join_events((hipStream_t)stream, (hipStream_t)aux_stream, &ev_fork, &ev_join)) return FBL_ERR_ARG;
           if (hipEventRecord(ev_fork, (hipStream_t)stream) != hipSuccess) return FBL_ERR_ARG;
-          if (hipStreamWaitEvent(rem_stream, ev_fork, 0) != hipSuccess) return FBL_ERR_ARG;
-          s_rem = (void*)rem_stream;
+          if (hipStreamWaitEvent((hipStream_t)aux_stream, ev_fork, 0) != hipSuccess) return FBL_ERR_ARG;
+          s_rem = aux_stream;
           forked = true;
         }
         const size_t aux_es = (aux_kind == FBL_AUX_ADD_F32) ? 4 : 2;
@@ -501,7 +523,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                               1, nullptr, (rem_mode & 2) ? -3 : -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, s_rem, seg_n,
                               seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big);
         if (rc) return rc;
-        if (forked && hipEventRecord(ev_join, rem_stream) != hipSuccess) return FBL_ERR_ARG;
+        if (forked && hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess) return FBL_ERR_ARG;
         rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
                           out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
                           p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0);
@@ -661,10 +683,10 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                                 int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                                 int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
-                                void* stream) {
+                                void* stream, void* aux_stream) {
   return gemm_nt_impl(A, lda, B, ldb, M, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32, out_bf16,
                       out_pre_bf16, ldc, batch, strideA, strideB, strideC, strideAux, strideBias, splitk, splitk_ws,
-                      splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream);
+                      splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream, 0, nullptr, 0, 0, aux_stream);
 }
 
 // z[M, A] = dropout(relu(x[M,K] . Wd[A,K]^T + bd)): the adapter's down-projection with ReLU AND dropout in the GEMM
@@ -685,11 +707,12 @@ extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void*
 // must not straddle the segment boundary); the 256-wide tiles additionally need N1 % 256 == 0 and are not used otherwise.
 extern "C" int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1,
                                           int A, int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy,
-                                          float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream) {
+                                          float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream,
+                                          void* aux_stream) {
   if (A <= 0 || (N1 & 63)) return FBL_ERR_ARG;
   return gemm_nt_impl(x_bf16, ldx, wm_bf16, ldw, M, N1 + A, K, bias_m, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_NONE, nullptr, 0,
                       y_f32, y_bf16, nullptr, ldy, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, N1,
-                      z_bf16, ldz);
+                      z_bf16, ldz, 0, aux_stream);
 }
 
 extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

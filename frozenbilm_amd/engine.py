@@ -78,6 +78,8 @@ class Engine:
         self._pack_frozen()
         self._relidx: Dict[int, torch.Tensor] = {}
         self.reducer = None  # set by parallel.GradReducer for data-parallel training
+        self.params_version = 0  # bumped by FusedAdam.step (which updates the flat buffer through raw pointers)
+        self._ops_version = None
         self.skip_dead_layer = True
         self._ln_ws = L.ln_bwd_ws(self.H, dev)
         self._cs_ws = L.colsum_ws(max(self.H, self.I), dev)
@@ -85,6 +87,10 @@ class Engine:
         # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
         # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
         self.side = torch.cuda.Stream(device=dev)  # (stream priorities were measured: no effect on the interference)
+        # the caller-provided aux stream of the GEMM entry points (remainder rows of multi-round problems run there,
+        # concurrently with the big tiles; include/fbl.h): one per device, owned by the host side
+        if L._AUX.get(dev.index if dev.index is not None else torch.cuda.current_device()) is None:
+            L.set_aux_stream(torch.cuda.Stream(device=dev), dev)
         # reference-faithful switch: fill the full [N, V] logits in every forward even when only the loss is consumed
         self.eager_logits = os.environ.get("FBL_EAGER_LOGITS", "0") == "1"
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
@@ -161,8 +167,10 @@ class Engine:
         # composed rows Wd.W change with every optimizer step and are rebuilt by two batched GEMMs per site type
         # (refresh_trainable_operands).  For those, the transposed frozen weights of all layers live in one tensor, in
         # REVERSE layer order (index j = nL-1-layer) -- the order of the adapters in the flat trainable buffer.
-        self.merge1 = bool(self.A1) and self.A1 % 8 == 0 and H % 4 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
-        self.merge2 = bool(self.A2) and self.A2 % 8 == 0 and H % 4 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
+        # (the merged GEMM needs the bottleneck unpadded, A % 64 == 0, and the segment boundary H on a wave's column
+        # range, H % 64 == 0: include/fbl.h; otherwise neither the composed weights nor their per-step rebuild exist)
+        self.merge1 = bool(self.A1) and self.A1 % 64 == 0 and H % 64 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
+        self.merge2 = bool(self.A2) and self.A2 % 64 == 0 and H % 64 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
         self.WoT_rev = torch.empty(nL, H, H, dtype=BF16, device=dev)
         self.WdT_rev = torch.empty(nL, I, H, dtype=BF16, device=dev)
         if self.merge1:
@@ -229,6 +237,11 @@ class Engine:
             v = rel_index_vector(S, self.cfg.position_buckets, self.cfg.max_rel, self.cfg.att_span)
             self._relidx[S] = torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
         return self._relidx[S]
+
+    def invalidate_operands(self):
+        """the trainable parameters were modified in a way the engine cannot see (through `.data`): rebuild on next use"""
+        self._ops_version = None
+        self.params_version += 1
 
     def refresh_trainable_operands(self):
         """bf16 MFMA operands of the trainable matrices (they change every optimizer step)."""
@@ -394,7 +407,14 @@ class Engine:
         run.mask = mask.view(-1)
         run.labels = full_labels
         run.rows = rows_labelled if full_labels is not None else None
-        self.refresh_trainable_operands()
+        # bf16 operands / composed adapter rows follow the trainable parameters.  An inference forward skips the rebuild
+        # when nothing wrote to them since the last one: writers are FusedAdam.step (params_version) and in-place updates
+        # through the parameter objects (their autograd version counters: torch optimizers, p.copy_()).  Code that
+        # writes through `.data` behind autograd's back calls engine.invalidate_operands().
+        ver = (self.params_version, tuple(self.named[n]._version for n in self.order)) if not need_grad else None
+        if ver is None or ver != self._ops_version:
+            self.refresh_trainable_operands()
+            self._ops_version = ver
         use_ans = bool(m.n_ans) and not mlm
         if logit_rows is not None:
             if need_grad or full_labels is not None:

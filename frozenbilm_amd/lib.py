@@ -24,9 +24,9 @@ _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
-                              _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp]),
+                              _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp, _vp]),
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
-    "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp]),
+    "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
@@ -93,6 +93,30 @@ def _p(t: Optional[torch.Tensor]):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# The caller-provided aux stream of the two GEMM entry points that can use one (include/fbl.h).  The library owns no
+# stream: the engine creates one per device and registers it here; the bindings pass it only when the launch goes to the
+# stream it was registered for (its device's current stream at registration: the training stream) and never while that
+# would make a launch wait on itself.
+_AUX = {}
+
+
+def set_aux_stream(stream: Optional["torch.cuda.Stream"], device=None):
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if stream is None:
+        _AUX.pop(idx, None)
+    else:
+        _AUX[idx] = stream
+
+
+def _aux_stream():
+    st = _AUX.get(torch.cuda.current_device())
+    if st is None:
+        return None
+    h = st.cuda_stream
+    return None if h == torch.cuda.current_stream().cuda_stream else h
 
 
 def _chk(code: int, name: str):
@@ -168,7 +192,7 @@ def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, a
     code = load().fbl_gemm_bf16_nt(_p(A), lda, _p(B), ldb, M, N, K, _p(bias), _p(rowscale), float(alpha), act, aux_kind,
                                    _p(aux), ld_aux, _p(out_f32), _p(out_bf16), _p(out_pre), ldc or 0, batch, sA, sB, sC,
                                    sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), int(a_kblock),
-                                   _p(kskip_len), int(kskip_steps), _stream())
+                                   _p(kskip_len), int(kskip_steps), _stream(), _aux_stream())
     _chk(code, "fbl_gemm_bf16_nt")
 
 
@@ -199,7 +223,8 @@ def dense_adapter_down_fwd(x, wm, bias_m, N1, z, *, y_f32=None, y_bf16=None, p_d
             assert ldy is None or ldy == l
             ldy = l
     _chk(load().fbl_dense_adapter_down_fwd(_p(x), ldx, _p(wm), ldw, M, N1, A, K, _p(bias_m), _p(y_f32), _p(y_bf16), ldy or 0,
-                                           float(p_drop), int(seed), _p(z), ldz, _stream()), "fbl_dense_adapter_down_fwd")
+                                           float(p_drop), int(seed), _p(z), ldz, _stream(), _aux_stream()),
+         "fbl_dense_adapter_down_fwd")
 
 
 def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):

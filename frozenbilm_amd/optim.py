@@ -56,6 +56,7 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = grp["betas"]
         L.adam_flat(flat, g, self._m, self._v, grp["lr"], b1, b2, grp["eps"], grp["weight_decay"], self._step, sumsq_t=ss,
                     max_norm=clip_max_norm or 0.0, grad_scale=grad_scale)
+        eng.params_version += 1  # the bf16 operand copies of the engine are stale now
 
     def grad_norm(self) -> torch.Tensor:
         """global L2 norm of the last clipped step's gradients (device scalar)"""

@@ -6,7 +6,12 @@
  * per function as "ref: file:line".  Conventions:
  *   - extern "C", plain device pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*.
  *   - every function only enqueues work on `stream` (graph-capturable: no malloc/free/sync inside) and returns
- *     0 on success, a positive hipError_t, or a negative FBL_ERR_* code for argument errors.
+ *     0 on success, a positive hipError_t, or a negative FBL_ERR_* code for argument errors.  The library owns no
+ *     stream and reads no environment variable.  Two GEMM entry points take an optional caller-provided `aux_stream`
+ *     (see fbl_gemm_bf16_nt): work put there is forked from and joined back into `stream` by events inside the call,
+ *     so after the call everything still depends only on `stream` -- also under stream capture.  Those events (one
+ *     pair per (stream, aux_stream) pair, created on first use on the calling thread's current device, mutex-guarded)
+ *     are the only process state of the library; calls on different streams may come from different threads.
  *   - bf16 tensors are raw uint16 storage (torch.bfloat16), fp32 are float, indices int64/int32 as stated.
  *   - row-major; `ld*` are row strides in ELEMENTS.
  */
@@ -48,6 +53,9 @@ int fbl_abi_version(void);
  * multiplied -- the rows of G^T beyond a sample's last valid position (fbl_disent_attn_bwd_shear leaves them unwritten).
  * a_kblock_stride > 0: A is k-blocked, A[m][k] lives at m*lda + (k/32)*a_kblock_stride + k%32 (the G^T layout written
  * by fbl_disent_attn_bwd_shear, lda = 32); 0 = plain K-contiguous rows.
+ * aux_stream (may be NULL): a second stream of the caller on the same device.  A multi-round problem runs its last,
+ * partly filled round as small tiles; with an aux stream those are launched there first, concurrently with the big tiles
+ * (fork / join by events inside this call).  NULL: they simply precede the big tiles on `stream`.
  * ref: every nn.Linear on the path -- model/deberta.py:255,311,329,757-765,847-853,994,1545,1550;
  *      model/adapter.py:38,42; conv1d deberta.py:397 (as K=3H GEMM); and their autograd dX/dW. */
 int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
@@ -55,7 +63,7 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
                      float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len,
-                     int kskip_steps, void* stream);
+                     int kskip_steps, void* stream, void* aux_stream);
 
 /* Host-side query, no launch: the kernel fbl_gemm_bf16_nt uses for a plain (K-contiguous, no k-skip) problem of this
  * shape: 8 = the 8-phase 256x256 / 224x256 kernel (gemm8_kernel; remainder rows of a multi-round problem run as 64x128
@@ -81,7 +89,7 @@ int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, i
  * ref: model/deberta.py:255-257, 329-331 (dense -> adapter) + model/adapter.py:38-41. */
 int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1, int A,
                                int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
-                               uint64_t seed, void* z_bf16, int64_t ldz, void* stream);
+                               uint64_t seed, void* z_bf16, int64_t ldz, void* stream, void* aux_stream);
 
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold

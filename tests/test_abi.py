@@ -50,6 +50,16 @@ def test_library_exports_every_symbol(libpath):
     assert handle.fbl_colsum_ws_floats(100) == 512 * 100
 
 
+def test_product_library_reads_no_environment(libpath):
+    """The experiment switches (FBL_GEMM_*, FBL_ATTN_*) exist only in FBL_DEBUG_BUILD=1 builds: the product library
+    does not even import getenv, and owns no stream (no hipStreamCreate*: helper streams are caller-provided)."""
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--undefined-only", libpath], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    assert "hipStreamCreate" not in syms
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from frozenbilm_amd import lib
 

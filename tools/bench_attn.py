@@ -102,8 +102,23 @@ def timeit(f, n=20):
     return s.elapsed_time(e) * 1e3 / n
 
 
+side = torch.cuda.Stream()
+ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+
+
+def shear_both():  # the two shear passes are independent: second one on a side stream
+    ev0.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ev0)
+        shear1()
+        ev1.record()
+    shear0()
+    torch.cuda.current_stream().wait_event(ev1)
+
+
 fwd()
 prep()
-res = {n: timeit(f) for n, f in (("fwd", fwd), ("prep", prep), ("bwd_a", bwd_a), ("shear0", shear0), ("shear1", shear1))}
+res = {n: timeit(f) for n, f in (("fwd", fwd), ("prep", prep), ("bwd_a", bwd_a), ("shear0", shear0), ("shear1", shear1),
+                                 ("shear0||1", shear_both))}
 tag = f"order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
-print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total {sum(res.values()) - res['fwd']:.1f}us")
+print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total {sum(res.values()) - res['fwd'] - res['shear0||1']:.1f}us")
