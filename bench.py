@@ -51,6 +51,16 @@ def algorithmic_flops_per_sample(S=266, H=1536, I=6144, A=192, P=512, V=128100, 
     return fwd, bwd
 
 
+def executed_flops_per_sample(S=266, H=1536, I=6144, A=192, P=512, V=128100, T=10, F=1024, rows_labelled=0.0, layers=24):
+    """What the loss-only step really runs (per sample): no dead in-encoder pass of the last layer (layers + 1 layer
+    executions instead of layers + 2), the vocabulary GEMM (forward and backward) on the labelled rows only."""
+    layer = 24 * S * H * H + 8 * S * H * A + 4 * S * S * H + 4 * S * P * H
+    fwd = (layers + 1) * layer + 6 * S * H * H + 2 * T * F * H + 2 * S * H * H + 2 * rows_labelled * H * V
+    layer_bwd = 24 * S * H * H + 2 * (8 * S * H * A + 4 * S * S * H + 4 * S * P * H)
+    bwd = (layers + 1) * layer_bwd + 6 * S * H * H + 2 * (2 * T * F * H) + 2 * S * H * H + 2 * rows_labelled * H * V
+    return fwd, bwd
+
+
 def synth_batch(B, T, F, L, V, seed, device):
     g = torch.Generator().manual_seed(seed)
     video = torch.randn(B, T, F, generator=g).half().float()
@@ -219,9 +229,16 @@ def main():
 
         d = timed(fwd_only, n_x)
         model.train()
+        rows_lab = float((batch["labels"] != -100).sum().item()) / B
+        ex_f, ex_b = executed_flops_per_sample(S=S, rows_labelled=rows_lab, layers=args.layers)
         extras["eval_forward"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
                                   "algorithmic_tflops": fwd_f * B / d / 1e12, "frac_of_peak": fwd_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
-                                  "note": "eval-mode forward with labels (loss on the labelled rows; logits filled on access)"}
+                                  "executed_tflops": ex_f * B / d / 1e12, "executed_frac_of_peak": ex_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
+                                  "note": "eval-mode forward with labels (loss on the labelled rows; logits filled on access). "
+                                          "algorithmic_* divides the reference's op list (SURVEY 8d: full-vocabulary head on every "
+                                          "row, dead layer-23 pass) by the time; executed_* counts only what this forward ran "
+                                          "(vocabulary GEMM on the labelled rows, 25 layer executions)"}
+        extras["executed_tflops_per_step"] = (ex_f + ex_b) * B / 1e12
         # host cost of one step where the GPU cannot hide it: the same launch sequence on a B=1 batch
         small = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=77, device=dev)
         keep = dict(batch)

@@ -1,0 +1,62 @@
+"""One rank of the two-rank data-parallel check of the HIP engine (launched by tests/test_gpu_model.py).
+
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv[1] = output file (rank 0 writes it).
+
+Backend: nccl (= RCCL) with one GPU per rank when the box has at least WORLD_SIZE GPUs, otherwise gloo with every rank on
+cuda:0 -- the same engine / GradReducer code path either way (bucketed async all-reduce of the flat trainable gradient
+buffer launched from inside the backward pipeline, 1/world scaling in finish()).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    multi = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if multi else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl" if multi else "gloo", init_method="env://", world_size=world, rank=rank)
+
+    from frozenbilm_amd.parallel import GradReducer
+    from oracle import deberta_oracle as O
+    from tests.golden.make_goldens import _tiny_cfg, synth_batch
+    from tests.test_gpu_model import build
+
+    cfg = _tiny_cfg()
+    m = build(cfg, O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1))  # eval mode: dropout off, gradients on
+    m.to(dev)
+    red = GradReducer.attach(m, min_bucket_elems=1 << 10)  # small buckets: several collectives in flight during backward
+    per = 2
+    batch = synth_batch(cfg, B=per * world, L=60, seed=9)
+    mine = {k: v[rank * per:(rank + 1) * per].to(dev) for k, v in batch.items()}
+    losses = []
+    for _ in range(2):  # two steps: the reducer's cursor / bucket bookkeeping must reset between them
+        m.zero_grad(set_to_none=False)
+        out = m(**mine)
+        out.loss.backward()  # the engine's backward launches the bucket collectives and joins them (GradReducer.finish)
+        losses.append(out.loss.item())
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    n_coll = len(red.last_launched)
+    # every rank must hold the same reduced gradients
+    flat = torch.cat([g.reshape(-1) for g in grads.values()]).to(dev)
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    same = bool(torch.equal(ref, flat))
+    ok = torch.tensor([1.0 if same else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        torch.save({"grads": grads, "losses": losses, "backend": dist.get_backend(), "collectives": n_coll,
+                    "ranks_agree": bool(ok.item() == 1.0), "world": world}, sys.argv[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

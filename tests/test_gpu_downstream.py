@@ -226,3 +226,114 @@ def test_mask_row_head_and_batched_candidates_match_the_reference_shaped_path(go
     ref = _j(g, "eval_results")
     flips = sum(int(results[k]["pred"] != ref[str(k)]["pred"]) for k in results)
     assert flips <= 1, flips
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 4 / 5 at FULL size
+def _full_size_setup(n_ans, B, Lt, seed):
+    """DeBERTa-v2-XLarge (24 layers) + adapters with an answer head, and a synthetic batch of BASELINE's shape: T = 10 x 1024
+    features, ragged texts of up to Lt tokens with exactly one [MASK] each (what bench.py --workload videoqa / mc feeds)."""
+    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
+
+    cfg = DebertaV2Config()
+    torch.manual_seed(seed)
+    m = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1, n_ans=n_ans)
+    m.to(DEV).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    a2tok = torch.randint(5, cfg.vocab_size, (n_ans, 5), generator=g)
+    a2tok = a2tok * (torch.arange(5)[None] < torch.randint(1, 6, (n_ans, 1), generator=g))
+    m.set_answer_embeddings(a2tok.to(DEV))
+    MASK = 128000
+
+    class Tok:
+        mask_token_id, pad_token_id, sep_token_id = MASK, 0, 2
+
+        def __call__(self, text, **kw):
+            ids = torch.stack(text)
+            return {"input_ids": ids, "attention_mask": (ids != 0).long()}
+
+    def texts(s):
+        gg = torch.Generator().manual_seed(s)
+        tlen = torch.randint(Lt // 8, Lt + 1, (B,), generator=gg)
+        tlen[-1] = Lt
+        ids = torch.randint(5, 127000, (B, Lt), generator=gg) * (torch.arange(Lt)[None] < tlen[:, None])
+        ids[torch.arange(B), torch.stack([torch.randint(1, int(t), (1,), generator=gg) for t in tlen]).view(-1)] = MASK
+        return list(ids)
+
+    video = torch.randn(B, 10, 1024, generator=g).half().float()
+    vlen = torch.randint(1, 11, (B,), generator=g)
+    import types
+
+    args = types.SimpleNamespace(max_feats=10, use_video=True, suffix="", use_context=True, max_tokens=Lt, print_freq=10 ** 9)
+    return m, Tok(), texts, video, vlen, args
+
+
+def _sub(batch, sl):
+    out = {}
+    for k, v in batch.items():
+        if k == "text" and isinstance(v[0], list):
+            out[k] = [c[sl] for c in v]
+        else:
+            out[k] = v[sl]
+    return out
+
+
+@pytest.mark.slow
+def test_full_size_videoqa_config4_batch_independence():
+    """BASELINE config 4 at its full size (24 layers, B = 32, L = 256, n_ans = 1000, head on the [MASK] rows): the
+    product's `videoqa.evaluate` on the whole batch returns, question for question, what it returns on the two halves --
+    answer logits within 1e-3 and the same top-10 answer ids wherever neighbouring candidates are separated by more."""
+    B = 32
+    m, tok, texts, video, vlen, args = _full_size_setup(1000, B, 256, seed=21)
+    batch = dict(video=video, video_len=vlen, qid=list(range(B)), type=[0] * B, text=texts(11),
+                 answer_id=torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(3)))
+
+    def logits_of(bd):
+        from frozenbilm_amd.loops import tokenize, video_inputs
+
+        v, vm = video_inputs(bd, torch.device(DEV))
+        enc = tokenize(tok, bd["text"], args)
+        with torch.no_grad():
+            return P_vqa.answer_logits(m, tok, enc["input_ids"], args, video=v, video_mask=vm, input_ids=enc["input_ids"].to(DEV),
+                                       attention_mask=enc["attention_mask"].to(DEV)).float()
+
+    full = logits_of(batch)
+    halves = torch.cat([logits_of(_sub(batch, slice(0, 16))), logits_of(_sub(batch, slice(16, 32)))], 0)
+    assert full.shape == (B, 1000) and torch.isfinite(full).all()
+    err = (full - halves).abs().max().item()
+    print(f"config 4 full size: max |logit(B=32) - logit(2 x B=16)| = {err:.2e}")
+    assert err < 1e-3, err
+    top_f, top_h = full.topk(11, -1), halves.topk(11, -1)
+    gaps = (top_f.values[:, :-1] - top_f.values[:, 1:]).min(-1).values  # smallest separation among the first 11 candidates
+    clear = gaps > 4 * err + 1e-6
+    assert clear.float().mean().item() > 0.5
+    assert torch.equal(top_f.indices[clear][:, :10], top_h.indices[clear][:, :10])  # answer indices bit-exact
+    # and through the loop itself: same per-question predictions and metrics
+    res_f, out_f = P_vqa.evaluate(m, tok, ListLoader([batch]), torch.device(DEV), "msrvtt", args, thresholds=[1, 10])
+    res_h, out_h = P_vqa.evaluate(m, tok, ListLoader([_sub(batch, slice(0, 16)), _sub(batch, slice(16, 32))]), torch.device(DEV),
+                                  "msrvtt", args, thresholds=[1, 10])
+    for q in range(B):
+        if bool(clear[q]):
+            assert res_f[q]["pred"] == res_h[q]["pred"], q
+    assert abs(out_f["acc1"] - out_h["acc1"]) <= (~clear).sum().item() / B + 1e-9
+
+
+@pytest.mark.slow
+def test_full_size_mc_config5_candidates_in_one_forward():
+    """BASELINE config 5 at its full size (24 layers, B = 8, 4 candidates, S = 512): the scores of `mc.candidate_scores`
+    -- all 32 candidate rows in ONE forward -- equal the reference's one-forward-per-candidate loop (mc.py:140-165,
+    `mc_sequential`) within 1e-3, and the chosen candidate is the same wherever the margin is larger."""
+    B, C = 8, 4
+    m, tok, texts, video, vlen, args = _full_size_setup(2, B, 502, seed=31)
+    batch = dict(video=video, video_len=vlen, qid=list(range(B)), type=[0] * B, text=[texts(11 + c) for c in range(C)],
+                 answer_id=torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(4)))
+    with torch.no_grad():
+        one = P_mc.candidate_scores(m, tok, batch, torch.device(DEV), args).float()
+        args.mc_sequential = True
+        seq = P_mc.candidate_scores(m, tok, batch, torch.device(DEV), args).float()
+    assert one.shape == (B, C) and torch.isfinite(one).all()
+    err = (one - seq).abs().max().item()
+    print(f"config 5 full size: max |score(one forward) - score(per candidate)| = {err:.2e}")
+    assert err < 1e-3, err
+    s2 = seq.topk(2, -1).values
+    clear = (s2[:, 0] - s2[:, 1]) > 4 * err + 1e-6
+    assert torch.equal(one.argmax(-1)[clear], seq.argmax(-1)[clear])

@@ -373,16 +373,26 @@ def _rel_fro(a, b):
     return (a - b).norm().item() / max(b.norm().item(), 1e-12)
 
 
-def test_gradients_vs_bf16_operand_oracle_tight():
+def _tight_cfgs():
+    xl = O.OracleConfig()  # true xlarge dimensions (H=1536, 24 heads, I=6144, adapters 192, F=1024) ...
+    xl.num_hidden_layers = 4  # ... with a reduced layer count and vocabulary so the CPU oracle finishes in seconds
+    xl.vocab_size = 4096
+    return [pytest.param(_tiny_cfg(), 8, 120, id="tiny"), pytest.param(xl, 2, 96, id="xlarge-dims-4-layers", marks=pytest.mark.slow)]
+
+
+@pytest.mark.parametrize("cfg,B,Lt", _tight_cfgs())
+def test_gradients_vs_bf16_operand_oracle_tight(cfg, B, Lt):
     """Every trainable gradient against the oracle run with the HIP path's arithmetic contract (matrix-multiply operands
     rounded to bf16, fp32 accumulation: oracle.bf16_operands) AND the ReLU gates the GPU run took (oracle.adapter_gates,
     read from the saved bottleneck activations).  That removes the one discontinuity through which rounding noise turns
     into a 10 % difference of d(adapter.down): every gradient, adapter.down included, must then agree to a few per cent
-    -- a 10 % systematic error in dW_down, which the 25 % bound against the pure-fp32 reference cannot see, fails here."""
-    cfg = _tiny_cfg()
-    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    -- a 10 % systematic error in dW_down, which the 25 % bound against the pure-fp32 reference cannot see, fails here.
+    Runs at the tiny configuration and at the true xlarge dimensions (H = 1536, 64-wide heads, I = 6144, 192-wide
+    bottlenecks, merged dense + adapter-down GEMMs on the 8-phase tiles) with 4 layers."""
+    tiny = cfg.hidden_size < 1024
+    P = O.synth_params(cfg, seed=41, std=0.05 if tiny else 0.02, ln_jitter=0.1)
     m = build(cfg, P)
-    batch = synth_batch(cfg, B=8, L=120, seed=7)
+    batch = synth_batch(cfg, B=B, L=Lt, seed=7)
     for k, v in P.items():
         v.requires_grad_(O.is_trainable(k))
     out = m(**to_dev(batch))
@@ -391,7 +401,7 @@ def test_gradients_vs_bf16_operand_oracle_tight():
     for sv in out.__dict__["_run"].layers:
         gates += [(sv.z1[:, : cfg.hidden_size // cfg.ds_factor_attn] > 0).cpu(), (sv.z2[:, : cfg.hidden_size // cfg.ds_factor_ff] > 0).cpu()]
     out.loss.backward()
-    with O.bf16_operands(), O.adapter_gates([g_.view(8, -1, g_.shape[-1]) for g_ in gates]):
+    with O.bf16_operands(), O.adapter_gates([g_.view(B, -1, g_.shape[-1]) for g_ in gates]):
         ref = O.forward(P, cfg, **batch)
         ref["loss"].backward()
     assert abs(out.loss.item() - ref["loss"].item()) < 5e-3
@@ -651,3 +661,59 @@ def test_grad_reducer_on_the_hip_engine_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path):
+    """Two processes, one rank each, over RCCL (nccl backend, one GPU per rank) when the box has two GPUs and over gloo
+    with both ranks on cuda:0 otherwise: the gradients left in p.grad after backward + GradReducer.finish() equal the
+    single-process gradients of the same four samples under the DDP loss convention (mean over ranks of the per-rank mean
+    loss) -- same kernels, same inputs, so to fp32 rounding -- on every rank, over two consecutive steps, with several
+    bucket collectives launched from inside the backward pipeline."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    world = 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    out_file = str(tmp_path / "dp.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), out_file], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            o, _ = p_.communicate()
+        logs.append(o)
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(logs)
+    got = torch.load(out_file)
+    assert got["ranks_agree"] and got["world"] == world and got["collectives"] >= 3, {k: got[k] for k in ("ranks_agree", "collectives")}
+    print(f"backend {got['backend']}, {got['collectives']} bucket collectives per step")
+    # single process: the two half batches, gradients accumulated and averaged (DDP convention)
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = synth_batch(cfg, B=4, L=60, seed=9)
+    m.zero_grad(set_to_none=False)
+    losses = []
+    for r in range(world):
+        out = m(**{k: v[2 * r:2 * r + 2].to(DEV) for k, v in batch.items()})
+        out.loss.backward()
+        losses.append(out.loss.item())
+    assert abs(got["losses"][0] - losses[0]) < 1e-6 and abs(got["losses"][1] - losses[0]) < 1e-6  # rank 0's own loss, both steps
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            ref = p.grad.float().cpu() / world
+            worst = max(worst, _rel_fro(got["grads"][n], ref))
+    print(f"worst relative difference reduced-vs-single-process: {worst:.2e}")
+    assert worst < 1e-5, worst
