@@ -447,7 +447,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) F.y[kk * 4 + dt] = *(const bf16x8*)(ytb + (long)(dt * 16) * a.y_sd + c0 + kk * 32);
+      for (int dt = 0; dt < 4; ++dt)
+        F.y[kk * 4 + dt] = (FBL_ATTN_DBGBITS & 2048) ? z8 : *(const bf16x8*)(ytb + (long)(dt * 16) * a.y_sd + c0 + kk * 32);
     F.x[0] = *(const bf16x8*)(a.X + xbase + c0 + g * 8);
     F.x[1] = *(const bf16x8*)(a.X + xbase + c0 + 32 + g * 8);
   };
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.y[kk * 4 + dt], xv, acc[dt], 0, 0, 0);
       const int cb = c0 + kk * 32;  // this lane's columns: cb + g*8 + e
+      if (FBL_ATTN_DBGBITS & 512) continue;  // (debug builds: no scatter)
       if (band) {
         const int s0 = NEG ? (lin0 + cb) : (lin0 - cb);
 #pragma unroll
@@ -530,9 +532,11 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     if (rb >= 0 && rb < a.rcnt && !(FBL_ATTN_DBGBITS & 128))
       *(bf16x4*)(gt + (long)rb * 32 + w * 16 + g * 4) = (bf16x4){f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
   };
+  // (a third k-step of fragments in flight, and 64-row workgroups of four waves, were measured: no gain / slower)
   bf16x8 pa[4], pb[4];
+  const int nks_run = (FBL_ATTN_DBGBITS & 1024) ? 0 : nks;
   load_pt(0, pa);
-  for (int kk = 0; kk < nks; kk += 2) {
+  for (int kk = 0; kk < nks_run; kk += 2) {
     if (kk + 1 < nks) load_pt(kk + 1, pb);
     table_step(kk, pa);
     if (kk + 2 < nks) load_pt(kk + 2, pa);
