@@ -67,7 +67,7 @@ struct BwdAArgs {
 // forward (attn_fwd.hip) the position tables are not staged: each wave owns two of the eight 16-row tiles of the pair's
 // table window, loads their MFMA A-fragments from global memory once and multiplies them against every query group
 // (T1) and key group (T2) whose sub-window contains the tile.
-constexpr int LTW = 104;                         // fp16 row stride of the T1/T2 tiles (6 row tiles = 96 used)
+constexpr int LTW = 100;                         // fp16 row stride of the T1/T2 tiles (6 row tiles = 96 used): 50 dwords, 16 rows -> 16 banks
 constexpr int A_QS = 0;                          // [64 i][64] swz
 constexpr int A_DOS = A_QS + 8192;               // [64 i][64] swz
 constexpr int A_KS = A_DOS + 8192;               // [64 j][64] swz (staged once)

@@ -50,7 +50,7 @@ struct AttnArgs {
 // EVERY query group (T1, B = the groups' Q fragments out of the Q tile) and every key group (T2, B = K fragments out of
 // the K tile) whose sub-window contains the tile -- 5 + 5 MFMA pairs per wave and table as before, but 8 instead
 // of 20 fragment loads per wave, every table byte fetched once per workgroup and no LDS window (32 KiB less).
-constexpr int LTW = 104;                        // fp16 row stride of the T1/T2 tiles (6 row tiles = 96 used)
+constexpr int LTW = 100;                        // fp16 row stride of the T1/T2 tiles (6 row tiles = 96 used): 50 dwords, 16 rows -> 16 banks
 constexpr int SM_KS = 0;                        // [64 keys][64] bf16 swizzled
 constexpr int SM_VS = SM_KS + 8192;             // [64 keys][64] bf16 swizzled (read transposed by ds_read_b64_tr_b16)
 constexpr int SM_T1 = SM_VS + 8192;             // [64 queries][LTW] fp16

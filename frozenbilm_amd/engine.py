@@ -477,7 +477,10 @@ class Engine:
         dropout seed).  Merged form: one GEMM gives the dense output and the adapter bottleneck."""
         H, dev = self.H, self.dev
         o32 = torch.empty(N, H, dtype=F32, device=dev)
-        ob = torch.empty(N, H, dtype=BF16, device=dev)
+        # the bf16 copy of the dense output is the adapter's GEMM operand: with the merged GEMM (the bottleneck comes out
+        # of the same launch) only the backward reads it -- an inference forward does not write it (26 MB per site)
+        need_ob = run.save or ent is None or not (merged and ent["Ap"] == A)
+        ob = torch.empty(N, H, dtype=BF16, device=dev) if need_ob else None
         if ent is None:
             L.gemm(x_bf16, W[wkey], bias=W[bkey], out_f32=o32, out_bf16=ob)
             return o32, ob, None, 0
