@@ -325,7 +325,8 @@ def run_downstream(args):
     batch = dict(video=video.to(dev), video_len=vlen, qid=list(range(B)), type=[0] * B,
                  answer_id=torch.randint(0, n_ans if vqa else C, (B,), generator=g),
                  text=texts(11) if vqa else [texts(11 + c) for c in range(C)])
-    largs = types.SimpleNamespace(max_feats=T, use_video=True, suffix="", use_context=True, max_tokens=Lt, print_freq=10 ** 9)
+    largs = types.SimpleNamespace(max_feats=T, use_video=True, suffix="", use_context=True, max_tokens=Lt, print_freq=10 ** 9,
+                                  inference_graphs=os.environ.get("FBL_NO_INFERENCE_GRAPHS", "0") != "1")
 
     class Loader(list):
         dataset = list(range(B))
@@ -359,7 +360,8 @@ def run_downstream(args):
            "data": "synthetic",
            "config": {"workload": f"BASELINE configs[{3 if vqa else 4}]: DeBERTa-v2-XLarge({args.layers}L)+adapters, B={B}, T=10x1024, L={Lt} "
                                   f"(S={S}), n_ans={n_ans}, {C} candidate(s) per question in ONE forward of {B * C} samples, eval loop "
-                                  "incl. host-side result bookkeeping, head on the [MASK] rows only"},
+                                  "incl. host-side result bookkeeping, head on the [MASK] rows only",
+                      "inference_graphs": len(model.__dict__.get("_graph_cache", {}))},
            "candidate_forwards_per_s": B * C * args.steps / dt, "algorithmic_tflops": tf, "frac_of_peak": tf / PEAK_BF16_TFLOPS}
     print(json.dumps(out))
 

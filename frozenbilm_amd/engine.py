@@ -78,6 +78,7 @@ class Engine:
         self._pack_frozen()
         self._relidx: Dict[int, torch.Tensor] = {}
         self.reducer = None  # set by parallel.GradReducer for data-parallel training
+        self._pad_bufs = {}
         self.params_version = 0  # bumped by FusedAdam.step (which updates the flat buffer through raw pointers)
         self._ops_version = None
         self.skip_dead_layer = True
@@ -238,6 +239,23 @@ class Engine:
             self._relidx[S] = torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
         return self._relidx[S]
 
+    def _refresh_if_stale(self, need_grad: bool):
+        ver = (self.params_version, tuple(self.named[n]._version for n in self.order)) if not need_grad else None
+        if ver is None or ver != self._ops_version:
+            self.refresh_trainable_operands()
+            self._ops_version = ver
+
+    def prepare_inference(self):
+        """Everything an inference forward needs from OUTSIDE its launch sequence, done now: the bf16 operand copies /
+        composed adapter rows are current (rebuilt in place: a captured graph keeps reading the same buffers) and the
+        current stream has waited for the side stream that composes them (a captured forward may not wait on events
+        recorded outside its capture, so `_compose_ev` is consumed here)."""
+        self._refresh_if_stale(False)
+        ev = getattr(self, "_compose_ev", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev[1])
+            self._compose_ev = None
+
     def invalidate_operands(self):
         """the trainable parameters were modified in a way the engine cannot see (through `.data`): rebuild on next use"""
         self._ops_version = None
@@ -257,8 +275,10 @@ class Engine:
                 Ap = _ru(A, 64)
                 down = self.Pb[p + blk + ".down.weight"]  # [A,H]
                 up = self.Pb[p + blk + ".up.weight"]  # [H,A]
-                if Ap != A:
-                    upp = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
+                if Ap != A:  # zero-padded copy in a persistent buffer (stable address: captured graphs keep reading it)
+                    upp = self._pad_bufs.get((i, key))
+                    if upp is None:
+                        upp = self._pad_bufs[(i, key)] = torch.zeros(H, Ap, dtype=BF16, device=self.dev)
                     upp[:, :A] = up
                     up = upp
                 ent[key] = dict(down=down, up=up, A=A, Ap=Ap, name=p + blk,
@@ -277,7 +297,9 @@ class Engine:
         if self.F:
             wv = self.Pb["deberta.embeddings.linear_video.weight"]
             if self.Fp != self.F:
-                w2 = torch.zeros(H, self.Fp, dtype=BF16, device=self.dev)
+                w2 = self._pad_bufs.get("Wv")
+                if w2 is None:
+                    w2 = self._pad_bufs["Wv"] = torch.zeros(H, self.Fp, dtype=BF16, device=self.dev)
                 w2[:, : self.F] = wv
                 wv = w2
             self.Wv = wv
@@ -411,10 +433,7 @@ class Engine:
         # when nothing wrote to them since the last one: writers are FusedAdam.step (params_version) and in-place updates
         # through the parameter objects (their autograd version counters: torch optimizers, p.copy_()).  Code that
         # writes through `.data` behind autograd's back calls engine.invalidate_operands().
-        ver = (self.params_version, tuple(self.named[n]._version for n in self.order)) if not need_grad else None
-        if ver is None or ver != self._ops_version:
-            self.refresh_trainable_operands()
-            self._ops_version = ver
+        self._refresh_if_stale(need_grad)
         use_ans = bool(m.n_ans) and not mlm
         if logit_rows is not None:
             if need_grad or full_labels is not None:

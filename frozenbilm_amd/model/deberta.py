@@ -223,6 +223,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         emb = self._module("deberta.embeddings")
         emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
         self._engine = None
+        self.inference_graphs = False  # opt-in: replay the `logit_rows` inference forward as one hipGraph (_graph_forward)
         self._reducer = None  # parallel.GradReducer attached to this model (survives engine rebuilds)
         self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
         self._seed_salt = None  # torch seed (args.seed + rank in the reference's main()) and rank, fixed at first use
@@ -289,6 +290,7 @@ class DebertaV2ForMaskedLM(nn.Module):
     def invalidate(self):
         """Drop the packed bf16 operands / flat buffers (after load_state_dict, .to(), set_answer_embeddings)."""
         self._engine = None
+        self.__dict__.pop("_graph_cache", None)  # captured graphs hold the old engine's buffers
 
     def _load_from_state_dict(self, *a, **k):
         self.invalidate()
@@ -329,6 +331,73 @@ class DebertaV2ForMaskedLM(nn.Module):
             self._seed_salt = ((torch.initial_seed() & 0xFFFFFFFF) * 2654435761 + rank * 40503 + 12345) & 0xFFFFFFFFFFFF
         return (self.step_seed * 1000003 + self._seed_salt) & 0xFFFFFFFFFFFF
 
+    # ---------------------------------------------------------------- inference launch graphs (opt-in)
+    GRAPH_L_BUCKET = 32  # text lengths are padded up to a multiple of this inside the graph path
+    GRAPH_CACHE = 6      # captured (batch, length, rows) configurations kept per model
+
+    def _graph_forward(self, eng, input_ids, attention_mask, video, video_mask, mlm, logit_rows):
+        """The `logit_rows` inference forward (what `videoqa.evaluate` / `mc.evaluate` run per batch, videoqa.py:157-168,
+        mc.py:160-172) as ONE hipGraph replay: ~700 kernel launches cost the host ~10 ms per batch when issued one by one,
+        more than the loops have to spare next to an 18 ms forward.  The text is padded to the next multiple of
+        GRAPH_L_BUCKET with pad tokens (masked: a sample's logits do not depend on padding), the inputs are copied into
+        the graph's static buffers, the graph -- captured on first use of a (batch, padded length, frames, rows)
+        configuration, least recently used ones dropped -- is replayed and the [rows, V] logits are returned as a copy.
+        Returns None when the configuration cannot be captured (the caller then takes the eager path)."""
+        import torch.nn.functional as F_
+
+        # operands of the trainable weights / composed adapter rows are rebuilt (in place) outside the graph when needed
+        eng.prepare_inference()
+        B, Lt = input_ids.shape
+        T = video.shape[1] if (video is not None and eng.F) else 0
+        Lp = min(-(-Lt // self.GRAPH_L_BUCKET) * self.GRAPH_L_BUCKET, self.config.max_position_embeddings - T)
+        if Lp < Lt:
+            return None
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        rows = logit_rows.to(eng.dev).long().view(-1)
+        S_old, S_new = T + Lt, T + Lp
+        rows = (rows // S_old) * S_new + rows % S_old
+        key = (id(eng), B, Lp, T, video_mask is not None, rows.numel(), bool(mlm))
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        feed = dict(input_ids=F_.pad(input_ids, (0, Lp - Lt), value=self.config.pad_token_id),
+                    attention_mask=F_.pad(attention_mask, (0, Lp - Lt), value=0), rows=rows.to(torch.int32))
+        if T:
+            feed["video"] = video
+            if video_mask is not None:
+                feed["video_mask"] = video_mask
+        ent = cache.pop(key, None)
+        if ent is None:
+            for k in [k for k in cache if k[0] != id(eng)]:
+                del cache[k]
+            while len(cache) >= self.GRAPH_CACHE:
+                del cache[next(iter(cache))]
+            static = {k: v.to(eng.dev).clone() for k, v in feed.items()}
+
+            def run_once():
+                return eng.run(static["input_ids"], static["attention_mask"], static.get("video"), static.get("video_mask"),
+                               None, mlm, False, logit_rows=static["rows"])["logits"]
+
+            run_once()  # warm-up outside the capture (lazy initialisation, allocator)
+            torch.cuda.synchronize(eng.dev)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    logits = run_once()
+            except Exception as e:  # noqa: BLE001
+                import warnings
+
+                torch.cuda.synchronize(eng.dev)
+                warnings.warn(f"inference graph capture failed ({type(e).__name__}: {e}); staying on the eager path")
+                self.inference_graphs = False
+                return None
+            ent = (graph, static, logits)
+        graph, static, logits = ent
+        cache[key] = ent  # most recently used last
+        for k, v in feed.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return logits.clone()
+
     def forward(
         self,
         input_ids=None,
@@ -358,6 +427,12 @@ class DebertaV2ForMaskedLM(nn.Module):
         if output_attentions:
             raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
         eng = self.engine()
+        if (self.inference_graphs and logit_rows is not None and labels is None and not output_hidden_states
+                and not self.training and not torch.is_grad_enabled()):
+            logits = self._graph_forward(eng, input_ids, attention_mask, video, video_mask, mlm, logit_rows)
+            if logits is not None:
+                out = MaskedLMOutput(loss=None, logits=logits, hidden_states=None, attentions=None)
+                return out if return_dict is not False else (logits,)
         res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states, logit_rows=logit_rows)
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
                              attentions=None)

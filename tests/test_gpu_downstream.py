@@ -337,3 +337,50 @@ def test_full_size_mc_config5_candidates_in_one_forward():
     s2 = seq.topk(2, -1).values
     clear = (s2[:, 0] - s2[:, 1]) > 4 * err + 1e-6
     assert torch.equal(one.argmax(-1)[clear], seq.argmax(-1)[clear])
+
+
+def test_inference_graph_replay_matches_the_eager_forward(golden):
+    """`model.inference_graphs = True`: the [MASK]-row inference forward of the evaluate loops runs as one hipGraph replay
+    (text padded to the length bucket, inputs copied into static buffers).  Replays reproduce the eager logits to the
+    batch-independence tolerance (the padded length changes tile shapes), give IDENTICAL results when the same batch is
+    replayed, follow a parameter update made between two replays, and a second batch shape gets its own graph."""
+    g = golden("G10_videoqa", raw=True)
+    cfg, P, m = hip_model(N_ANS, 10, g["a2tok"])
+    tok, args = StubTokenizer(cfg.vocab_size), Args(max_feats=cfg.max_feats)
+    batches = make_videoqa_batches(cfg.vocab_size, cfg.max_feats, cfg.features_dim, N_ANS, 3, 4, seed=101, dataset_name="msrvtt")
+
+    def logits_of(bd):
+        from frozenbilm_amd.loops import tokenize, video_inputs
+
+        v, vm = video_inputs(bd, torch.device(DEV))
+        enc = tokenize(tok, bd["text"], args)
+        with torch.no_grad():
+            return P_vqa.answer_logits(m, tok, enc["input_ids"], args, video=v, video_mask=vm, input_ids=enc["input_ids"].to(DEV),
+                                       attention_mask=enc["attention_mask"].to(DEV)).float()
+
+    eager = [logits_of(b) for b in batches]
+    m.inference_graphs = True
+    first = [logits_of(b) for b in batches]
+    assert m.inference_graphs, "capture failed"
+    again = [logits_of(b) for b in batches]
+    for e, a, b in zip(eager, first, again):
+        assert a.shape == e.shape and (a - e).abs().max().item() < 2e-3, (a - e).abs().max().item()
+        assert torch.equal(a, b)  # a replay is deterministic
+    assert len(m.__dict__["_graph_cache"]) >= 1
+    # a parameter update between replays is picked up (operands are rebuilt in place, outside the graph)
+    with torch.no_grad():
+        p = m.get_param("deberta.encoder.layer.1.output.adapter.up.bias")
+        p.add_(torch.linspace(-0.3, 0.3, p.numel(), device=p.device))  # (a uniform shift would vanish in the LayerNorm)
+    m.inference_graphs = False
+    moved_eager = logits_of(batches[0])
+    m.inference_graphs = True
+    moved_graph = logits_of(batches[0])
+    assert (moved_eager - eager[0]).abs().max().item() > 1e-3
+    assert (moved_graph - moved_eager).abs().max().item() < 2e-3
+    # the evaluate loop itself with the switch on returns the same predictions
+    args.inference_graphs = True
+    res_g, out_g = P_vqa.evaluate(m, tok, ListLoader(batches), torch.device(DEV), "msrvtt", args, thresholds=[1, 10])
+    m.inference_graphs = False
+    args.inference_graphs = False
+    res_e, out_e = P_vqa.evaluate(m, tok, ListLoader(batches), torch.device(DEV), "msrvtt", args, thresholds=[1, 10])
+    assert out_g == out_e and all(res_g[q]["pred"][0] == res_e[q]["pred"][0] for q in res_e)
