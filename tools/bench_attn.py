@@ -30,6 +30,8 @@ pqk = (torch.randn(span2, 2 * H, generator=g) * 0.7).to(torch.bfloat16).to(dev)
 T = 10
 tl = torch.randint(32, S - T + 1, (B,), generator=g)
 tl[-1] = S - T
+if os.environ.get("FULL") == "1":  # every sample at full length: no empty workgroups, no load imbalance
+    tl[:] = S - T
 vl = torch.randint(1, T + 1, (B,), generator=g)
 mask = torch.zeros(B, S, dtype=torch.int32)
 for b in range(B):
@@ -120,5 +122,6 @@ fwd()
 prep()
 res = {n: timeit(f) for n, f in (("fwd", fwd), ("prep", prep), ("bwd_a", bwd_a), ("shear0", shear0), ("shear1", shear1),
                                  ("shear0||1", shear_both))}
-tag = f"order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
+npairs = int(sum(((int(k) + 63) // 64) ** 2 for k in klen.tolist()) * nh)
+tag = f"pairs={npairs} order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
 print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total {sum(res.values()) - res['fwd'] - res['shear0||1']:.1f}us")
