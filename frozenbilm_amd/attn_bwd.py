@@ -1,6 +1,6 @@
 """Host-side orchestration of the disentangled-attention backward (see csrc/attn_bwd.hip for the math).
 
-    dO --rowdot--> D            K,Q --head_transpose--> K^T, Q^T (head-major [nh,64,B,Sp])
+    prep     : D = rowdot(dO, O); K^T, Q^T (head-major [nh,64,B,Sp]); PK^T, PQ^T   (one launch)
     kernel A : dV, dS, dS^T
     shear(0) : dQ = dS.K   + G1.PK   (+ G1^T)        shear(1) : dK = dS^T.Q + G2.PQ   (+ G2^T)
     GEMM     : dPK[h] = G1^T[h] . Q^T[h]^T           GEMM     : dPQ[h] = G2^T[h] . K^T[h]^T     (split-K, per head)
@@ -33,19 +33,16 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     border = getattr(run, "border", None)
     scale = 1.0 / math.sqrt(64 * 3)
 
-    # (folding D_i = dO_i . O_i into kernel A was measured: +43 us there for the O tiles on its critical path vs 8 us here)
+    # One launch prepares the backward: K^T, Q^T (head-major), PK^T, PQ^T and D_i = dO_i . O_i.  (Folding D into kernel A
+    # was measured: +43 us there for the O tiles on its critical path; five separate small launches: 65 us in situ.)
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
-    L.attn_rowdot(dctx, sv.ctx, Dv, B, S, nh)
     KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
-    L.head_transpose(k, KT, B, S, Sp, nh, head_major=True)
-    L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
-    dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
-    dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
-    L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
-    L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
+    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2)
+    dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
+    dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
     from .model.relpos import rel_index_vector
     rv = rel_index_vector(S, eng.cfg.position_buckets, eng.cfg.max_rel, eng.cfg.att_span) if hasattr(eng, "cfg") else None

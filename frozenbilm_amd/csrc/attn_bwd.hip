@@ -48,6 +48,100 @@ __global__ void rowdot_kernel(const bf16* dO, const bf16* O, long ld, float* out
   }
 }
 
+// ------------------------------------------------------------------------------------------- backward preparation
+// Everything the backward needs before kernel A as ONE launch instead of five: the position-contiguous copies K^T, Q^T
+// (head-major [nh,64,B,Sp]: operands of the shear passes and of the position-table gradient GEMMs), PK^T, PQ^T
+// ([nh,64,span2]) and D = rowdot(dO, O).  Five small kernels (two of them 1.5 MB each, i.e. pure launch latency) cannot
+// fill the chip one after the other; as block ranges of one grid they run side by side.
+struct PrepArgs {
+  const bf16* q; const bf16* k; long ldq;
+  const bf16* pq; const bf16* pk; long ldp;
+  const bf16* dO; const bf16* O; long ldo;
+  bf16* QT; bf16* KT; bf16* PQT; bf16* PKT; float* Dv;
+  int B, S, Sp, nh, span2;
+  int n_tr, n_tab;  // blocks of one K / Q transpose, of one table transpose
+};
+
+// vt[h*sh + b*sb + d*sd + s] = v[b*S+s, h*64+d] (s < S), 0 for S <= s < Sp: one (64-position tile, head, sample)
+__device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* v, long ldv, bf16* vt, int S, int Sp, long sh,
+                                                    long sb, long sd, int s0, int h, int b) {
+  const int t = threadIdx.x;
+  {
+    const int row = t >> 2, c0 = (t & 3) * 2;
+    const int s = s0 + row;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (s < S) x = *(const uint4*)(v + ((long)b * S + s) * ldv + h * 64 + (c0 + c) * 8);
+      uint32_t* d = tile + row * 33 + (c0 + c) * 4;
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
+  }
+  __syncthreads();
+  const uint16_t* t16 = (const uint16_t*)tile;
+  const int sc = t & 7;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int d = (t >> 3) + pass * 32;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t lo = t16[(sc * 8 + 2 * k) * 66 + d], hi = t16[(sc * 8 + 2 * k + 1) * 66 + d];
+      w[k] = lo | (hi << 16);
+    }
+    const int s = s0 + sc * 8;
+    if (s < Sp) *(uint4*)(vt + h * sh + b * sb + d * sd + s) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
+  __shared__ uint32_t tile[64 * 33];
+  int id = blockIdx.x;
+  if (id < 2 * a.n_tr) {  // K^T (first n_tr blocks) and Q^T, head-major
+    const bool isq = id >= a.n_tr;
+    if (isq) id -= a.n_tr;
+    const int nst = a.Sp / 64;
+    const int st = id % nst, h = (id / nst) % a.nh, b = id / (nst * a.nh);
+    head_transpose_tile(tile, isq ? a.q : a.k, a.ldq, isq ? a.QT : a.KT, a.S, a.Sp, 64l * a.B * a.Sp, a.Sp, (long)a.B * a.Sp,
+                        st * 64, h, b);
+    return;
+  }
+  id -= 2 * a.n_tr;
+  if (id < 2 * a.n_tab) {  // PK^T, PQ^T: [nh][64][span2]
+    const bool isq = id >= a.n_tab;
+    if (isq) id -= a.n_tab;
+    const int nst = a.span2 / 64;
+    const int st = id % nst, h = id / nst;
+    head_transpose_tile(tile, isq ? a.pq : a.pk, a.ldp, isq ? a.PQT : a.PKT, a.span2, a.span2, 64l * a.span2,
+                        (long)a.nh * 64 * a.span2, a.span2, st * 64, h, 0);
+    return;
+  }
+  id -= 2 * a.n_tab;
+  {  // D[b,h,s] = dO_row . O_row over the head's 64 columns: 8 lanes per (row, head)
+    const long gid = (long)id * 256 + threadIdx.x;
+    const long idx = gid >> 3;
+    const int c = (int)(gid & 7);
+    const long total = (long)a.B * a.S * a.nh;
+    const bool live = idx < total;
+    const long row = live ? idx / a.nh : 0;
+    const int h = live ? (int)(idx % a.nh) : 0;
+    float s = 0.f;
+    if (live) {
+      const bf16x8 x = *(const bf16x8*)(a.dO + row * a.ldo + h * 64 + c * 8);
+      const bf16x8 y = *(const bf16x8*)(a.O + row * a.ldo + h * 64 + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (live && c == 0) {
+      const int bb = (int)(row / a.S), ss = (int)(row % a.S);
+      a.Dv[((long)bb * a.nh + h) * a.S + ss] = s;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- kernel A
 struct BwdAArgs {
   const bf16* q; const bf16* k; const bf16* v; long ldq;  // row-major [B*S, ld], head h at col h*64
@@ -617,6 +711,21 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
     hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp,
+                                 const void* dO, const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT,
+                                 float* Dv, int B, int S, int Sp, int nh, int span2, void* stream) {
+  if (S < 1 || Sp < S || Sp % 64 || span2 <= 0 || span2 % 64) return FBL_ERR_SHAPE;
+  if ((ldq % 8) || (ldp % 8) || (ldo % 8)) return FBL_ERR_ALIGN;
+  if (B <= 0 || nh <= 0) return 0;
+  PrepArgs a{(const bf16*)q, (const bf16*)k, ldq, (const bf16*)pq, (const bf16*)pk, ldp, (const bf16*)dO, (const bf16*)O, ldo,
+             (bf16*)QT, (bf16*)KT, (bf16*)PQT, (bf16*)PKT, Dv, B, S, Sp, nh, span2, (Sp / 64) * nh * B, (span2 / 64) * nh};
+  const long n_dot = ((long)B * S * nh * 8 + 255) / 256;
+  const long grid = 2l * a.n_tr + 2l * a.n_tab + n_dot;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
     "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
                                  _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
+    "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
@@ -385,6 +386,17 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
                                     _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _p(ctx), ldo,
                                     _p(lse), B, S, Sp, nh, span2, int(lin), _stream()), "fbl_disent_attn_fwd")
+
+
+def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2):
+    """K^T, Q^T (head-major), PK^T, PQ^T and D = rowdot(dO, O) in one launch (see fbl.h)"""
+    ldq, ldp, ldo = _rows2d(q, "q"), _rows2d(pq, "pq"), _rows2d(dO, "dO")
+    assert _rows2d(k, "k") == ldq and _rows2d(pk, "pk") == ldp and _rows2d(O, "O") == ldo
+    for t in (QT, KT, PQT, PKT):
+        _req(t, torch.bfloat16, "transposed output")
+        assert t.is_contiguous()
+    _chk(load().fbl_attn_bwd_prep(_p(q), _p(k), ldq, _p(pq), _p(pk), ldp, _p(dO), _p(O), ldo, _p(QT), _p(KT), _p(PQT), _p(PKT),
+                                  _p(Dv), B, S, Sp, nh, span2, _stream()), "fbl_attn_bwd_prep")
 
 
 def attn_rowdot(dO, O, out, B, S, nh):

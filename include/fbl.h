@@ -220,6 +220,12 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
  * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
  * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
+/* The preparation of one attention backward as ONE launch: QT / KT = fbl_head_transpose of q / k (head-major
+ * [nh,64,B,Sp]), PQT / PKT = the same of the position projections ([nh,64,span2]), Dv = fbl_attn_rowdot(dO, O).
+ * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D). */
+int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp, const void* dO,
+                      const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT, float* Dv, int B, int S, int Sp,
+                      int nh, int span2, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                            const int32_t* border, const float* lse, const float* Dv,

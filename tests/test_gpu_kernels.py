@@ -364,6 +364,30 @@ def test_head_transpose(L):
         assert (got[..., S:] == 0).all()
 
 
+def test_attn_bwd_prep_equals_the_separate_launches(L):
+    """fbl_attn_bwd_prep = four head transposes + rowdot in one launch: bit-identical to the stand-alone entry points"""
+    B, S, nh, span2 = 3, 150, 4, 512
+    H, Sp = nh * 64, 192
+    qkv = bf(rnd(B * S, 3 * H, seed=1)).to(BF16)
+    pqk = bf(rnd(span2, 2 * H, seed=2)).to(BF16)
+    dO, O = bf(rnd(B * S, H, seed=3)).to(BF16), bf(rnd(B * S, H, seed=4)).to(BF16)
+    q, k, pq, pk = qkv[:, :H], qkv[:, H:2 * H], pqk[:, :H], pqk[:, H:]
+    mk = lambda *shape: torch.full(shape, 7.0, dtype=BF16, device=DEV)
+    QT, KT, PQT, PKT = mk(nh, 64, B, Sp), mk(nh, 64, B, Sp), mk(nh, 64, span2), mk(nh, 64, span2)
+    Dv = torch.full((B, nh, S), 7.0, device=DEV)
+    L.attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2)
+    QT2, KT2, PQT2, PKT2 = mk(nh, 64, B, Sp), mk(nh, 64, B, Sp), mk(nh, 64, span2), mk(nh, 64, span2)
+    Dv2 = torch.empty(B, nh, S, device=DEV)
+    L.head_transpose(q, QT2, B, S, Sp, nh, head_major=True)
+    L.head_transpose(k, KT2, B, S, Sp, nh, head_major=True)
+    L.head_transpose(pq, PQT2, 1, span2, span2, nh, head_major=False)
+    L.head_transpose(pk, PKT2, 1, span2, span2, nh, head_major=False)
+    L.attn_rowdot(dO, O, Dv2, B, S, nh)
+    for a, b_, n in ((QT, QT2, "QT"), (KT, KT2, "KT"), (PQT, PQT2, "PQT"), (PKT, PKT2, "PKT"), (Dv, Dv2, "D")):
+        assert torch.equal(a, b_), n
+    assert (QT[:, :, :, S:] == 0).all()  # positions beyond S are zero-padded
+
+
 def test_cross_entropy(L):
     N, V = 37, 1003
     Vp = 1024

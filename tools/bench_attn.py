@@ -69,11 +69,14 @@ def fwd():
 
 
 def prep():
-    L.attn_rowdot(dctx, ctx, Dv, B, S, nh)
-    L.head_transpose(k, KT, B, S, Sp, nh, head_major=True)
-    L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
-    L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
-    L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
+    if os.environ.get("PREP_SPLIT") == "1":  # the five separate launches the fused preparation replaced
+        L.attn_rowdot(dctx, ctx, Dv, B, S, nh)
+        L.head_transpose(k, KT, B, S, Sp, nh, head_major=True)
+        L.head_transpose(q, QT, B, S, Sp, nh, head_major=True)
+        L.head_transpose(pk, PKT, 1, span2, span2, nh, head_major=False)
+        L.head_transpose(pq, PQT, 1, span2, span2, nh, head_major=False)
+    else:
+        L.attn_bwd_prep(q, k, pq, pk, dctx, ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2)
 
 
 def bwd_a():
