@@ -8,10 +8,11 @@
 //   dK = dS^T.Q + G2.PQ,    G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]        (p2c)
 //   dPK = sum_b G1^T.Q ,  dPQ = sum_b G2^T.K     (per head; done by the GEMM kernel on G1^T/G2^T written here)
 //
+// Prep      (attn_bwd_prep): D = rowdot(dO, O) and the position-contiguous copies K^T, Q^T, PK^T, PQ^T, one launch.
 // Kernel A  (attn_bwd_ds):  one workgroup per (b, h, 64-key tile), sweeps the query tiles; recomputes P exactly like
-//            the forward (sub-windowed fp16 T1/T2 bias GEMMs + LDS gather, same rounding) but with the KEYS as lane
+//            the forward (row-tile split fp16 T1/T2 bias GEMMs + LDS gather, same rounding) but with the KEYS as lane
 //            columns, so dV accumulates in registers; writes dS and dS^T (bf16, zero where masked) -- 2 x SxS bf16 per
-//            head is the only extra HBM.  Next query tile prefetched into registers while the current one is computed.
+//            head is the only extra HBM.
 // Kernel BC (attn_bwd_shear<NEG>): one workgroup per (b, h, 32 rows): X_out = dSx.Y + G.Ptab with the scatter
 //            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS stores / atomics into a [32 x W] bf16 tile, W =
 //            the index range the 32 rows can reach (~S+32 <= 512); also writes G^T for the position-table GEMMs.

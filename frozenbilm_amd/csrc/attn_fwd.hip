@@ -5,14 +5,16 @@
 //
 // One workgroup (4 waves) = one (batch, head, 64-query tile); it sweeps the keys in tiles of 64 with an online
 // softmax.  For a (query tile, key tile) pair idx(i-j) spans <= 127 consecutive rows of the position tables (idx is
-// monotone with slope <= 1), so both bias terms are MFMA GEMMs against a 128-row WINDOW of PK / PQ staged in LDS,
-//     T1[i][w] = Q_i . PKwin[w]   (per wave: its 16 queries need an 80-row sub-window)
-//     T2[j][w] = K_j . PQwin[w]   (per 16-key tile: 80-row sub-window; wave w computes key tile w, all waves read it)
+// monotone with slope <= 1), so both bias terms are MFMA GEMMs against a 128-row WINDOW of PK / PQ,
+//     T1[i][w] = Q_i . PKwin[w]   (a 16-query group needs an 80-row sub-window of it; 96 outside the identity band)
+//     T2[j][w] = K_j . PQwin[w]   (a 16-key group likewise)
 // followed by an LDS gather  c2p[i,j] = T1[i][idx(i-j)-..],  p2c[i,j] = T2[j][idx(i-j)-..].  Nothing of size SxS or
 // Sx512 ever reaches HBM.  All MFMAs are "swapped" (keys/positions as A rows, queries as B columns): a lane owns ONE
 // query column, so softmax statistics are in-lane + 2 shuffles, and P feeds the P.V MFMA straight from registers
-// (the k-slot order of that MFMA is permuted identically on the V^T operand).  The next key tile's global loads are
-// issued into registers before the current tile is computed (HBM/L2 latency hides under the MFMA + LDS work).
+// (the k-slot order of that MFMA is permuted identically on the V^T operand).  The window is never staged in LDS: see
+// the note at the kernel (row-tile split of the bias GEMMs); inside the identity band of the relative-position map the
+// gather addresses are lane constants + immediates (no index table).  Workgroups are dispatched longest sample first,
+// the tiles of one (sample, head) on one XCD (attn_common.h: wg_coord).
 #include "attn_common.h"
 #include "../../include/fbl.h"
 
