@@ -97,6 +97,8 @@ class Engine:
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
+        self.dw_on_side = os.environ.get("FBL_DW_SIDE", "0") == "1"  # A/B switch: generic dW route on the side stream
+        self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(os.environ.get("FBL_DW_GROUP", "16"))))  # adapter gradient products per launch (<= 16)
 
     # ------------------------------------------------------------------ parameter plumbing
     def _build_flat(self):
@@ -752,10 +754,20 @@ class Engine:
         sk = max(2, min(16, N // 512))
         nm = ent["name"]
 
-        def dw_work(ws, cs_ws):
+        if Ap <= 256 and H % 8 == 0 and not self.dw_on_side:
+            # dWu += dy^T z, dWd += dz^T x, dbd += colsum(dz) are NOT launched here: one adapter alone has 48 output tiles.
+            # The operands are parked until `dw_group` adapters are pending and go through ONE launch
+            # (fbl_adapter_bwd_dw: every tile walks all rows, no split-K round trip) on the MAIN stream -- its workgroups live
+            # for the whole pass, and a resident side-stream workgroup keeps the one-per-CU tiles of the big GEMMs off its CU.
+            # (up.bias's gradient colsum(dy) comes out of ln_bwd.)
+            run.dw_pending.append((A, nm, (dyb, z, dz, xin_b), run.dw_count))
+            run.dw_count += 1
+            return dx
+
+        def dw_work(ws, cs_ws):  # generic route, launched right away: bottlenecks wider than 256 (or FBL_DW_SIDE=1)
             L.gemm_tn_acc(dyb, z, self.G[nm + ".up.weight"], ws, N=A, splitk=sk)      # dWu[H,A] += dy^T z
             L.gemm_tn_acc(dz, xin_b, self.G[nm + ".down.weight"], ws, M=A, splitk=sk)  # dWd[A,H] += dz^T x
-            L.colsum(dz, self.G[nm + ".down.bias"], cs_ws, cols=A)  # up.bias grad = colsum(dy) comes from ln_bwd
+            L.colsum(dz, self.G[nm + ".down.bias"], cs_ws, cols=A)
 
         if self.use_side_stream:
             main = torch.cuda.current_stream()
@@ -771,6 +783,31 @@ class Engine:
         else:
             dw_work(self.sk_ws, self._cs_ws)
         return dx
+
+    def _dw_flush(self, run, red=None, force=False):
+        """Launch the parked adapter-gradient products (see _adapter_bwd) once `dw_group` of them are pending -- one
+        launch of 2 x H/64 workgroups per adapter; 16 adapters = 768 workgroups = three per CU, all resident -- or all of
+        them (force), and only then tell the gradient reducer about the stages whose buckets they complete.  An adapter
+        appears once per launch: the second execution of the last layer (enhanced mask decoder) waits for the next one,
+        so that no launch has a double-length tile."""
+        pend = run.dw_pending
+        while pend and (force or len(pend) >= self.dw_group):
+            take, names, rest = {}, set(), []
+            for rec in pend:
+                A, nm, seg, _ = rec
+                if nm in names or len(names) >= min(self.dw_group, L.ADW_MAX_ADAPTERS):
+                    rest.append(rec)
+                else:
+                    names.add(nm)
+                    take.setdefault(A, []).append((nm, seg))
+            for A, recs in take.items():
+                L.adapter_bwd_dw([([seg], self.G[nm + ".up.weight"], self.G[nm + ".down.weight"], self.G[nm + ".down.bias"])
+                                  for nm, seg in recs], A=A)
+            pend[:] = rest
+        if red is not None:  # a stage is final once every product parked before its end has been launched
+            lo = min((rec[3] for rec in pend), default=run.dw_count)
+            while run.dw_ready_keys and run.dw_ready_keys[0][1] <= lo:
+                red.ready(run.dw_ready_keys.pop(0)[0])
 
     def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
         """Backward of one layer execution.  dout: fp32 grad of its output.  Returns (dq_in, dkv_in) fp32 -- equal
@@ -888,6 +925,7 @@ class Engine:
         reducer = self.reducer
 
         red = _Ready(self, run, reducer) if reducer is not None else None
+        run.dw_pending, run.dw_ready_keys, run.dw_count = [], [], 0
         dq = torch.zeros(N, H, dtype=F32, device=dev)
         Vout = run.Vout
         Vp = _ru(Vout, 64)
@@ -910,8 +948,12 @@ class Engine:
             dlog[:, :Vout].copy_(gl)
             self._head_bwd(run, torch.arange(N, dtype=torch.int32, device=dev), dlog, dq, all_rows=True)
             del dlog
-        if red:
-            red.ready("head")
+
+        def stage_done(key):  # a stage's gradients are final once the adapter products parked in it have been launched
+            run.dw_ready_keys.append((key, run.dw_count))
+            self._dw_flush(run, red)
+
+        stage_done("head")
         run.dR = torch.zeros(self.span2, H, dtype=F32, device=dev)
         # ---- EMD: two executions of the last layer, newest first
         layers = run.layers
@@ -921,8 +963,7 @@ class Engine:
             dq, dkv = self._layer_bwd(run, sv, dq)
             d_kv_last = dkv if d_kv_last is None else d_kv_last.add_(dkv)
         dx = dq.add_(d_kv_last)  # q0 = pos_emb + hs[-2]: the query-stream grad flows into hs[-2] too
-        if red:
-            red.ready(f"layer{self.nL - 1}")
+        stage_done(f"layer{self.nL - 1}")
         # ---- encoder layers nL-2 .. 0
         while layers:
             sv = layers.pop()
@@ -930,12 +971,11 @@ class Engine:
                 dx, dcol = self._conv_bwd(run, dx)
                 dx, _ = self._layer_bwd(run, sv, dx)
                 L.col2im3(dcol, dx, B, S, H, 1)
-                if red:
-                    red.ready("conv")
+                stage_done("conv")
             else:
                 dx, _ = self._layer_bwd(run, sv, dx)
-            if red:
-                red.ready(f"layer{sv.li}")
+            stage_done(f"layer{sv.li}")
+        self._dw_flush(run, red, force=True)
         if getattr(run, "side_used", False):
             torch.cuda.current_stream().wait_stream(self.side)  # all adapter dW/db are in the flat grad buffer
         # ---- relative-position LayerNorm (receives grads from every layer execution)

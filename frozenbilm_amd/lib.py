@@ -28,6 +28,7 @@ SIGNATURES = {
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
+    "fbl_adapter_bwd_dw": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -238,6 +239,40 @@ def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):
     assert out_f32.shape[0] >= M and out_f32.shape[1] >= N
     _chk(load().fbl_gemm_bf16_tn_acc(_p(A), lda, _p(B), ldb, M, N, K, _p(out_f32), ldc, splitk, _p(ws), ws.numel(),
                                      _stream()), "fbl_gemm_bf16_tn_acc")
+
+
+ADW_MAX_ADAPTERS, ADW_MAX_SEGMENTS = 16, 24  # include/fbl.h
+
+
+def adapter_bwd_dw(groups, *, A):
+    """One launch for a group of same-shaped adapters.  groups: list of (segments, dWu, dWd, dbd), segments a list of
+    (dy [N,H], z [N,Ap], dz [N,Ap], x [N,H]) bf16 -- one per execution of that adapter in the forward pass;
+    dWu[H,A] += sum dy^T z, dWd[A,H] += sum dz^T x, dbd[A] += sum colsum(dz) (any of the three may be None)."""
+    segs = [sg for g in groups for sg in g[0]]
+    assert 0 < len(groups) <= ADW_MAX_ADAPTERS and 0 < len(segs) <= ADW_MAX_SEGMENTS
+    dy0, z0, dz0, x0 = segs[0]
+    N, H = dy0.shape
+    Ap = z0.shape[1]
+    lds = (_rows2d(dy0, "dy"), _rows2d(z0, "z"), _rows2d(dz0, "dz"), _rows2d(x0, "x"))
+    for dy, z, dz, x in segs:
+        for t, n in ((dy, "dy"), (z, "z"), (dz, "dz"), (x, "x")):
+            _req(t, torch.bfloat16, n)
+        assert dy.shape == (N, H) and x.shape == (N, H) and z.shape == (N, Ap) and dz.shape == (N, Ap) and Ap >= A
+        assert (_rows2d(dy, "dy"), _rows2d(z, "z"), _rows2d(dz, "dz"), _rows2d(x, "x")) == lds, "segments share row strides"
+    for _, dWu, dWd, dbd in groups:
+        for o, shp in ((dWu, (H, A)), (dWd, (A, H)), (dbd, (A,))):
+            if o is not None:
+                _req(o, torch.float32, "out")
+                assert tuple(o.shape) == shp and o.is_contiguous(), (tuple(o.shape), shp)
+    first = [0]
+    for g in groups:
+        first.append(first[-1] + len(g[0]))
+    seg_first = (C.c_int32 * len(first))(*first)
+    tab = lambda ts: (C.c_void_p * len(ts))(*[_p(t) for t in ts])
+    _chk(load().fbl_adapter_bwd_dw(len(groups), seg_first, tab([s[0] for s in segs]), tab([s[1] for s in segs]),
+                                   tab([s[2] for s in segs]), tab([s[3] for s in segs]), *lds, N, H, int(A), Ap,
+                                   tab([g[1] for g in groups]), tab([g[2] for g in groups]), tab([g[3] for g in groups]),
+                                   _stream()), "fbl_adapter_bwd_dw")
 
 
 # ------------------------------------------------------------------------------------------------ row ops

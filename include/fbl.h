@@ -91,6 +91,24 @@ int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_b
                                int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
                                uint64_t seed, void* z_bf16, int64_t ldz, void* stream, void* aux_stream);
 
+/* Weight and bias gradients of a GROUP of bottleneck adapters of one shape, accumulated (+=) by ONE launch:
+ *     dWu[o][H,A] += sum_s dy_s^T . z_s      dWd[o][A,H] += sum_s dz_s^T . x_s      dbd[o][A] += sum_s colsum(dz_s)
+ * over the segments s in [seg_first[o], seg_first[o+1]) of adapter o (one segment per execution of the adapter in the
+ * forward pass; seg_first: HOST array of n_adapters + 1 ints, seg_first[0] = 0).  dy_s, x_s: bf16 [N,H] (row strides ld_dy,
+ * ld_x); z_s = dropout(relu(down(x_s))), dz_s = grad of the bottleneck pre-activation: bf16 [N,Ap], Ap = A rounded up to 64
+ * (<= 256), columns A..Ap-1 zero.  The pointer tables (dy_bf16 .. x_bf16: one entry per segment; dWu, dWd, dbd: one entry
+ * per adapter, a table or an entry may be NULL) are HOST arrays of DEVICE pointers, read during the call.  Every output
+ * tile has one writer that walks all rows: no workspace, deterministic; the more adapters per call, the better the chip is
+ * filled (2 x ceil(H/64) workgroups per adapter).  Gradients are contiguous fp32.  ld_* and H multiples of 8.
+ * (up.bias's gradient colsum(dy) comes out of fbl_ln_bwd's `dysum`.)
+ * ref: autograd of model/adapter.py:38-42 (down, ReLU, dropout, up). */
+#define FBL_ADW_MAX_ADAPTERS 16
+#define FBL_ADW_MAX_SEGMENTS 24
+int fbl_adapter_bwd_dw(int n_adapters, const int32_t* seg_first, const void* const* dy_bf16, const void* const* z_bf16,
+                       const void* const* dz_bf16, const void* const* x_bf16, int64_t ld_dy, int64_t ld_z, int64_t ld_dz,
+                       int64_t ld_x, int N, int H, int A, int Ap, float* const* dWu, float* const* dWd, float* const* dbd,
+                       void* stream);
+
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
  * (splitk_ws >= splitk*M*roundup(N,4) floats, required).  M, N, lda, ldb multiples of 8; K arbitrary.

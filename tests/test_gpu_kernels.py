@@ -143,6 +143,44 @@ def test_gemm_splitk_accumulates_and_batched(L):
     assert (out[:, :64] == 0).all()
 
 
+@pytest.mark.parametrize("N,H,A,nad", [(8512, 1536, 192, 2), (333, 128, 16, 3), (1000, 200, 100, 1), (2100, 1536, 256, 16), (70, 64, 64, 2)])
+def test_adapter_bwd_dw(L, N, H, A, nad):
+    """dWu += dy^T z, dWd += dz^T x, dbd += colsum(dz) for a group of adapters in one launch (model/adapter.py:38-42
+    autograd): bench shape, a padded bottleneck (A = 16 -> Ap = 64; A = 100 -> 128), a ragged last 64-column tile (H = 200),
+    the widest bottleneck with the largest group, fewer rows than a row tile; the first adapter has TWO segments (an adapter
+    executed twice); strided wide operand; accumulation into pre-filled outputs; bit-reproducible; NULL outputs."""
+    Ap = (A + 63) // 64 * 64
+
+    def seg(seed):
+        dyf = torch.zeros(N, H + 64, dtype=BF16, device=DEV)  # strided wide operand (a column slice of a wider buffer)
+        dyf[:, :H] = bf(rnd(N, H, seed=seed))
+        xf = torch.zeros(N, H + 64, dtype=BF16, device=DEV)
+        xf[:, :H] = bf(rnd(N, H, seed=seed + 1))
+        z = torch.zeros(N, Ap, dtype=BF16, device=DEV); z[:, :A] = torch.relu(bf(rnd(N, A, seed=seed + 2)))
+        dz = torch.zeros(N, Ap, dtype=BF16, device=DEV); dz[:, :A] = bf(rnd(N, A, seed=seed + 3, scale=0.1))
+        return dyf[:, :H], z, dz, xf[:, :H]
+
+    segs = [[seg(100 * o + 10 * k) for k in range(2 if o == 0 else 1)] for o in range(nad)]
+    outs = []
+    for _ in range(2):
+        grp = [(segs[o], torch.full((H, A), 0.25, dtype=F32, device=DEV), torch.full((A, H), -0.5, dtype=F32, device=DEV),
+                torch.full((A,), 1.0, dtype=F32, device=DEV)) for o in range(nad)]
+        L.adapter_bwd_dw(grp, A=A)
+        outs.append(grp)
+    tol = dict(rtol=2e-3, atol=2e-3 * math.sqrt(2 * N))
+    for o in (0, nad - 1):
+        sg, dWu, dWd, dbd = outs[0][o]
+        close(dWu, 0.25 + sum(dy.float().t() @ z[:, :A].float() for dy, z, dz, x in sg), name="dWu", **tol)
+        close(dWd, -0.5 + sum(dz[:, :A].float().t() @ x.float() for dy, z, dz, x in sg), name="dWd", **tol)
+        close(dbd, 1.0 + sum(dz[:, :A].float().sum(0) for dy, z, dz, x in sg), name="dbd", **tol)
+    for ga, gb in zip(outs[0], outs[1]):
+        for a, b in zip(ga[1:], gb[1:]):
+            assert torch.equal(a, b)
+    only = torch.zeros(A, H, dtype=F32, device=DEV)  # any output may be NULL
+    L.adapter_bwd_dw([(segs[0], None, only, None)], A=A)
+    assert torch.equal(only, outs[0][0][2] + 0.5) or torch.allclose(only, outs[0][0][2] + 0.5, rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("K,M,N", [(8512, 1536, 192), (333, 192, 1536), (64, 16, 128), (1000, 128, 16)])
 def test_gemm_tn_accumulate(L, K, M, N):
     """C += A^T B with row-major operands (contraction over rows): the dW form, no transposed copies."""
