@@ -38,7 +38,7 @@ struct AdwArgs {
   AdwSeg seg[ADW_MAX_SEG];
   float* dWu[ADW_MAX_OUT]; float* dWd[ADW_MAX_OUT]; float* dbd[ADW_MAX_OUT];
   int seg_first[ADW_MAX_OUT + 1];  // adapter o owns segments [seg_first[o], seg_first[o+1])
-  long ld_dy, ld_z, ld_dz, ld_x;
+  int ld_dy[ADW_MAX_OUT], ld_z[ADW_MAX_OUT], ld_dz[ADW_MAX_OUT], ld_x[ADW_MAX_OUT];  // row strides, per adapter
   int N, H, A, tiles_h, n_out;
 };
 
@@ -57,7 +57,7 @@ __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h0 = th * WT;
-  const long ldw = WHICH ? g.ld_x : g.ld_dy, lds = WHICH ? g.ld_dz : g.ld_z;
+  const long ldw = WHICH ? g.ld_x[o] : g.ld_dy[o], lds = WHICH ? g.ld_dz[o] : g.ld_z[o];
   const int nk = (g.N + 63) / 64;
   const int s0 = g.seg_first[o], s1 = g.seg_first[o + 1];
   const int total = (s1 - s0) * nk;  // row tiles over all segments
@@ -245,16 +245,15 @@ __global__ __launch_bounds__(256, 2) void adapter_dw_kernel(AdwArgs g) {
 }  // namespace
 
 extern "C" int fbl_adapter_bwd_dw(int n_adapters, const int32_t* seg_first, const void* const* dy_bf16, const void* const* z_bf16,
-                                  const void* const* dz_bf16, const void* const* x_bf16, int64_t ld_dy, int64_t ld_z,
-                                  int64_t ld_dz, int64_t ld_x, int N, int H, int A, int Ap, float* const* dWu,
-                                  float* const* dWd, float* const* dbd, void* stream) {
+                                  const void* const* dz_bf16, const void* const* x_bf16, const int64_t* ld_dy,
+                                  const int64_t* ld_z, const int64_t* ld_dz, const int64_t* ld_x, int N, int H, int A, int Ap,
+                                  float* const* dWu, float* const* dWd, float* const* dbd, void* stream) {
   if (n_adapters <= 0 || N <= 0 || H <= 0 || A <= 0) return 0;
   if (n_adapters > ADW_MAX_OUT || !seg_first || seg_first[0] != 0) return FBL_ERR_ARG;
   const int nseg = seg_first[n_adapters];
   if (nseg <= 0 || nseg > ADW_MAX_SEG) return FBL_ERR_ARG;
   if (Ap < A || (Ap % 64) || Ap > 256 || (H % 8)) return FBL_ERR_SHAPE;
-  if ((ld_dy % 8) || (ld_z % 8) || (ld_dz % 8) || (ld_x % 8)) return FBL_ERR_ALIGN;
-  if (!dy_bf16 || !z_bf16 || !dz_bf16 || !x_bf16) return FBL_ERR_ARG;
+  if (!dy_bf16 || !z_bf16 || !dz_bf16 || !x_bf16 || !ld_dy || !ld_z || !ld_dz || !ld_x) return FBL_ERR_ARG;
   AdwArgs g{};
   for (int o = 0; o < n_adapters; ++o) {
     if (seg_first[o + 1] < seg_first[o]) return FBL_ERR_ARG;
@@ -262,13 +261,16 @@ extern "C" int fbl_adapter_bwd_dw(int n_adapters, const int32_t* seg_first, cons
     g.dWu[o] = dWu ? dWu[o] : nullptr;
     g.dWd[o] = dWd ? dWd[o] : nullptr;
     g.dbd[o] = dbd ? dbd[o] : nullptr;
+    if ((ld_dy[o] % 8) || (ld_z[o] % 8) || (ld_dz[o] % 8) || (ld_x[o] % 8)) return FBL_ERR_ALIGN;
+    if (ld_dy[o] < H || ld_x[o] < H || ld_z[o] < Ap || ld_dz[o] < Ap) return FBL_ERR_ARG;
+    if ((ld_dy[o] | ld_x[o] | ld_z[o] | ld_dz[o]) >> 24) return FBL_ERR_ARG;  // 64-row tile offsets stay inside 32 bits
+    g.ld_dy[o] = (int)ld_dy[o]; g.ld_z[o] = (int)ld_z[o]; g.ld_dz[o] = (int)ld_dz[o]; g.ld_x[o] = (int)ld_x[o];
   }
   g.seg_first[n_adapters] = nseg;
   for (int s = 0; s < nseg; ++s) {
     if (!dy_bf16[s] || !z_bf16[s] || !dz_bf16[s] || !x_bf16[s]) return FBL_ERR_ARG;
     g.seg[s] = AdwSeg{(const bf16*)dy_bf16[s], (const bf16*)z_bf16[s], (const bf16*)dz_bf16[s], (const bf16*)x_bf16[s]};
   }
-  g.ld_dy = ld_dy; g.ld_z = ld_z; g.ld_dz = ld_dz; g.ld_x = ld_x;
   g.N = N; g.H = H; g.A = A;
   g.tiles_h = (H + WT - 1) / WT;
   g.n_out = n_adapters;

@@ -169,6 +169,7 @@ constexpr int LNB_BLOCKS = 768;  // three 4-wave blocks per CU (the kernels run 
 struct LnBwdArgs {
   const float* dout; const int32_t* rowmask; const float* t; const float* stats; const float* gamma;
   float p_drop; uint64_t seed; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
+  long ld_dyb;  // row stride of out_dy_bf16 (elements)
 };
 template <int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         dys[e] += dy[c];
       }
       if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
-      if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * H + col, dy);
+      if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * a.ld_dyb + col, dy);
       if (a.out_dy_f32) stf<VEC>(a.out_dy_f32 + (long)row * H + col, dy);
     }
   }
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void ln_bwd2_kernel(LnBwdArgs a) {
           dys[e] += dy[c];
         }
         if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
-        if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * H + col, dy);
+        if (a.out_dy_bf16) stb<VEC>(a.out_dy_bf16 + (long)row * a.ld_dyb + col, dy);
         if (a.out_dy_f32) stf<VEC>(a.out_dy_f32 + (long)row * H + col, dy);
       }
     }
@@ -815,10 +816,12 @@ extern "C" int64_t fbl_ln_bwd_ws_floats(int H) { return (int64_t)LNB_BLOCKS * 3 
 extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats,
                           const float* gamma, float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16,
                           float* out_dy_f32, float* dgamma, float* dbeta, float* dysum, float* ws, int N, int H,
-                          void* stream) {
+                          int64_t ld_dy_bf16, void* stream) {
   if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
   if (N <= 0) return 0;
-  LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H};
+  if (ld_dy_bf16 == 0) ld_dy_bf16 = H;
+  if (ld_dy_bf16 < H || (ld_dy_bf16 % 8)) return FBL_ERR_ALIGN;
+  LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H, ld_dy_bf16};
   int nblk;
   if ((H / 64) % 2 == 0) {  // two waves per row, two rows per block iteration
     nblk = (N + 1) / 2;

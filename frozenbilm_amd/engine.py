@@ -97,6 +97,7 @@ class Engine:
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
+        self.fold_dx = os.environ.get("FBL_NO_FOLD_DX", "0") != "1"  # A/B switch: adapter dx folded into the dense dX GEMM
         self.dw_on_side = os.environ.get("FBL_DW_SIDE", "0") == "1"  # A/B switch: generic dW route on the side stream
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(os.environ.get("FBL_DW_GROUP", "16"))))  # adapter gradient products per launch (<= 16)
 
@@ -177,6 +178,10 @@ class Engine:
         self.WoT_rev = torch.empty(nL, H, H, dtype=BF16, device=dev)
         self.WdT_rev = torch.empty(nL, I, H, dtype=BF16, device=dev)
         if self.merge1:
+            # backward twin of the merged weights: dctx = [dy | dz] . [Wo^T | (Wd.Wo)^T]^T folds the adapter's dx = dy + dz.Wd
+            # into the dense layer's dX GEMM (K = H + A1, padded to an even number of 64-wide K tiles with zero columns)
+            self.Kf1 = _ru(H + self.A1, 128)
+            self.WoF_rev = torch.zeros(nL, H, self.Kf1, dtype=BF16, device=dev)
             self.WoM_rev = torch.zeros(nL, H + self.A1, H, dtype=BF16, device=dev)
             self.boM_rev = torch.zeros(nL, H + self.A1, dtype=F32, device=dev)
             self.bo16_rev = torch.zeros(nL, 1, H, dtype=BF16, device=dev)
@@ -207,6 +212,8 @@ class Engine:
                 self.boM_rev[j, :H].copy_(d["bo"])
                 self.bo16_rev[j, 0].copy_(d["bo"])
                 d["WoM"], d["boM"] = self.WoM_rev[j], self.boM_rev[j]
+                self.WoF_rev[j, :, :H].copy_(self.WoT_rev[j])
+                d["WoF"] = self.WoF_rev[j]
             if self.merge2:
                 self.WdM_rev[j, :H].copy_(d["Wd"])
                 self.bdM_rev[j, :H].copy_(d["bd"])
@@ -306,19 +313,19 @@ class Engine:
                 wv = w2
             self.Wv = wv
 
-    def _compose_adapter_down(self, events=False):
+    def _compose_adapter_down(self, events=False, grad=True):
         """Rows [H, H+A) of the merged weights / biases: Wd.W and Wd.b + bd for every layer (see _pack_frozen), from the
         current adapter weights.  Layers nL-1 .. 1 sit at a constant stride in the flat trainable buffer: one strided-batch
         GEMM each for the matrix and the bias; layer 0 (the conv LayerNorm sits between it and layer 1) gets its own and
         goes first.  events=True: returns (event after layer 0, event after everything) recorded on the current stream."""
         H, nL = self.H, self.nL
         sites = []
-        for on, blk, A, WT, WM, bM, b16 in ((self.merge1, ".attention.output.adapter", self.A1, self.WoT_rev,
-                                             getattr(self, "WoM_rev", None), getattr(self, "boM_rev", None),
-                                             getattr(self, "bo16_rev", None)),
-                                            (self.merge2, ".output.adapter", self.A2, self.WdT_rev,
-                                             getattr(self, "WdM_rev", None), getattr(self, "bdM_rev", None),
-                                             getattr(self, "bd16_rev", None))):
+        for on, blk, A, WT, WM, bM, b16, WF in ((self.merge1, ".attention.output.adapter", self.A1, self.WoT_rev,
+                                                 getattr(self, "WoM_rev", None), getattr(self, "boM_rev", None),
+                                                 getattr(self, "bo16_rev", None), getattr(self, "WoF_rev", None)),
+                                                (self.merge2, ".output.adapter", self.A2, self.WdT_rev,
+                                                 getattr(self, "WdM_rev", None), getattr(self, "bdM_rev", None),
+                                                 getattr(self, "bd16_rev", None), None)):
             if not on:
                 continue
             ow = [self.offsets[f"deberta.encoder.layer.{i}{blk}.down.weight"] for i in range(nL)]
@@ -328,25 +335,27 @@ class Engine:
                 groups = [(nL - 1, 1, ow[0], ob[0], A * H), (0, nL - 1, ow[nL - 1], ob[nL - 1], ow[nL - 2] - ow[nL - 1])]
             else:
                 groups = [(nL - 1 - i, 1, ow[i], ob[i], A * H) for i in range(nL)]
-            sites.append((A, WT, WM, bM, b16, groups))
+            sites.append((A, WT, WM, bM, b16, groups, WF))
 
-        def run_group(A, WT, WM, bM, b16, grp):
+        def run_group(A, WT, WM, bM, b16, grp, WF=None):
             j0, nb, o_w, o_b, st = grp
             wd3 = torch.as_strided(self.flat_bf16, (nb, A, H), (st, H, 1), o_w)
             L.gemm(wd3, WT[j0:j0 + nb], out_bf16=WM[j0:j0 + nb, H:H + A, :])                # Wd . W
+            if WF is not None and grad:  # (Wd . W)^T next to W^T: the K-extension of the folded backward GEMM
+                L.gemm(WT[j0:j0 + nb], wd3, out_bf16=WF[j0:j0 + nb, :, H:H + A])
             bd3 = torch.as_strided(self.flat, (nb, A, 1), (st, 1, 1), o_b)
             bo3 = torch.as_strided(bM, (nb, A, 1), (bM.stride(0), 1, 1), bM[j0, H:].storage_offset())
             L.gemm(wd3, b16[j0:j0 + nb], aux=bd3, aux_kind=L.AUX_ADD_F32, out_f32=bo3)      # Wd . b + bd
 
-        for A, WT, WM, bM, b16, groups in sites:  # layer 0 of every site first
-            run_group(A, WT, WM, bM, b16, groups[0])
+        for A, WT, WM, bM, b16, groups, WF in sites:  # layer 0 of every site first
+            run_group(A, WT, WM, bM, b16, groups[0], WF)
         ev0 = ev1 = None
         if events:
             ev0 = torch.cuda.Event()
             ev0.record()
-        for A, WT, WM, bM, b16, groups in sites:
+        for A, WT, WM, bM, b16, groups, WF in sites:
             for grp in groups[1:]:
-                run_group(A, WT, WM, bM, b16, grp)
+                run_group(A, WT, WM, bM, b16, grp, WF)
         if events:
             ev1 = torch.cuda.Event()
             ev1.record()
@@ -723,7 +732,7 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True, dysum=None, tail=0):
+    def _ln_bwd(self, name, dout, norm: NormRef, p_drop, seed, want_dy_bf16=True, dysum=None, tail=0, dy_out=None):
         """dysum: optional [H] accumulator for colsum(dy) = the bias gradient of whatever produced y (adapter up.bias).
         tail > 0: dt is the first N rows of a [N+tail, H] buffer whose tail is zeroed (aux operand of the dX GEMM that
         also produces the position-table gradient rows); the full buffer is returned as third value."""
@@ -732,7 +741,7 @@ class Engine:
         dt = dt_full[:N]
         if tail:
             dt_full[N:].zero_()
-        dyb = torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None
+        dyb = dy_out if dy_out is not None else (torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None)
         L.ln_bwd(dout, norm.t, norm.stats, norm.gamma, rowmask=norm.rowmask, p_drop=p_drop, seed=seed, out_dt=dt,
                  out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], dysum=dysum,
                  ws=self._ln_ws)
@@ -740,17 +749,24 @@ class Engine:
             return dt, dyb, dt_full
         return dt, dyb
 
-    def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed):
-        """Backward of _adapter_fwd.  dyb: grad of the adapter output (bf16 [N,H]); returns grad of its input (bf16)."""
+    def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed, dz_out=None):
+        """Backward of _adapter_fwd.  dyb: grad of the adapter output (bf16 [N,H]); returns grad of its input (bf16).
+        dz_out: the caller folds dx = dy + dz.Wd into the next GEMM ([dy | dz] operand, _layer_bwd): dz is written there
+        (a column slice of that operand), no dx is formed and None is returned."""
         N, H = dyb.shape
         A, Ap = ent["A"], ent["Ap"]
         dev = self.dev
         upT, downT = self._adapter_bwd_operands(ent)
-        dz = torch.zeros(N, Ap, dtype=BF16, device=dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=dev)
+        if dz_out is not None:
+            dz = dz_out
+        else:
+            dz = torch.zeros(N, Ap, dtype=BF16, device=dev) if Ap != A else torch.empty(N, Ap, dtype=BF16, device=dev)
         inv_keep = 1.0 / (1.0 - run.p_ad) if run.p_ad > 0 else 1.0
         L.gemm(dyb, upT, alpha=inv_keep, aux=z, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=dz, N=A)
-        dx = torch.empty(N, H, dtype=BF16, device=dev)
-        L.gemm(dz, downT, aux=dyb, aux_kind=L.AUX_ADD_BF16, out_bf16=dx)
+        dx = None
+        if dz_out is None:
+            dx = torch.empty(N, H, dtype=BF16, device=dev)
+            L.gemm(dz, downT, aux=dyb, aux_kind=L.AUX_ADD_BF16, out_bf16=dx)
         sk = max(2, min(16, N // 512))
         nm = ent["name"]
 
@@ -827,13 +843,27 @@ class Engine:
         da = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dh, W["WiT"], aux=dt2, aux_kind=L.AUX_ADD_F32, out_f32=da)
         del dh
-        dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
-                                dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None)
-        do = dy1
-        if "a1" in ad:
-            do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
         dctx = torch.empty(N, H, dtype=BF16, device=dev)
-        L.gemm(do, W["WoT"], out_bf16=dctx)
+        fold = "a1" in ad and self.fold_dx and "WoF" in W and ad["a1"]["Ap"] == ad["a1"]["A"]
+        if fold:
+            # dctx = dx . Wo with dx = dy + dz . Wd  ==  [dy | dz] . [Wo^T | (Wd.Wo)^T]^T: LayerNorm backward and the dz GEMM
+            # write the two column blocks of ONE operand and the dense dX GEMM runs with K = H + A (+ zero padding) -- the
+            # K = A GEMM that formed dx, its 26 MB output and its re-read are gone (25 us per layer execution)
+            A1 = ad["a1"]["A"]
+            dyz = torch.empty(N, self.Kf1, dtype=BF16, device=dev)
+            if self.Kf1 > H + A1:
+                dyz[:, H + A1:].zero_()  # finite values under the zero weight columns
+            dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
+                                    dysum=self.G[ad["a1"]["name"] + ".up.bias"], dy_out=dyz[:, :H])
+            self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1, dz_out=dyz[:, H:H + A1])
+            L.gemm(dyz, W["WoF"], out_bf16=dctx)
+        else:
+            dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
+                                    dysum=self.G[ad["a1"]["name"] + ".up.bias"] if "a1" in ad else None)
+            do = dy1
+            if "a1" in ad:
+                do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
+            L.gemm(do, W["WoT"], out_bf16=dctx)
         dqkv, pst = self._attn_bwd(run, sv, dctx)
         # position tables (off the critical path, side stream): dR += dropout_bwd([dPQ|dPK] . [Wq;Wk]), accumulated over
         # all layer executions; only encoder.LayerNorm's gamma/beta consume it, at the very end of backward
@@ -865,7 +895,7 @@ class Engine:
             else:
                 L.gemm(dpb, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
 
-        if self.use_side_stream:
+        if self.use_side_stream and os.environ.get("FBL_POS_MAIN") != "1":
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 work(self.side_ws)

@@ -28,14 +28,14 @@ SIGNATURES = {
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
-    "fbl_adapter_bwd_dw": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "fbl_adapter_bwd_dw": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
     "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                         _vp]),
     "fbl_ln_materialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "fbl_ln_bwd_ws_floats": (_l, [_i]),
-    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
     "fbl_im2col3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "fbl_col2im3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
@@ -250,15 +250,19 @@ def adapter_bwd_dw(groups, *, A):
     dWu[H,A] += sum dy^T z, dWd[A,H] += sum dz^T x, dbd[A] += sum colsum(dz) (any of the three may be None)."""
     segs = [sg for g in groups for sg in g[0]]
     assert 0 < len(groups) <= ADW_MAX_ADAPTERS and 0 < len(segs) <= ADW_MAX_SEGMENTS
-    dy0, z0, dz0, x0 = segs[0]
-    N, H = dy0.shape
-    Ap = z0.shape[1]
-    lds = (_rows2d(dy0, "dy"), _rows2d(z0, "z"), _rows2d(dz0, "dz"), _rows2d(x0, "x"))
-    for dy, z, dz, x in segs:
-        for t, n in ((dy, "dy"), (z, "z"), (dz, "dz"), (x, "x")):
-            _req(t, torch.bfloat16, n)
-        assert dy.shape == (N, H) and x.shape == (N, H) and z.shape == (N, Ap) and dz.shape == (N, Ap) and Ap >= A
-        assert (_rows2d(dy, "dy"), _rows2d(z, "z"), _rows2d(dz, "dz"), _rows2d(x, "x")) == lds, "segments share row strides"
+    N, H = segs[0][0].shape
+    Ap = segs[0][1].shape[1]
+    strides = []
+    for g in groups:
+        lds = None
+        for dy, z, dz, x in g[0]:
+            for t, n in ((dy, "dy"), (z, "z"), (dz, "dz"), (x, "x")):
+                _req(t, torch.bfloat16, n)
+            assert dy.shape == (N, H) and x.shape == (N, H) and z.shape == (N, Ap) and dz.shape == (N, Ap) and Ap >= A
+            l = (_rows2d(dy, "dy"), _rows2d(z, "z"), _rows2d(dz, "dz"), _rows2d(x, "x"))
+            assert lds is None or l == lds, "the segments of an adapter share their row strides"
+            lds = l
+        strides.append(lds)
     for _, dWu, dWd, dbd in groups:
         for o, shp in ((dWu, (H, A)), (dWd, (A, H)), (dbd, (A,))):
             if o is not None:
@@ -269,10 +273,11 @@ def adapter_bwd_dw(groups, *, A):
         first.append(first[-1] + len(g[0]))
     seg_first = (C.c_int32 * len(first))(*first)
     tab = lambda ts: (C.c_void_p * len(ts))(*[_p(t) for t in ts])
+    ldt = lambda k: (C.c_int64 * len(strides))(*[st[k] for st in strides])
     _chk(load().fbl_adapter_bwd_dw(len(groups), seg_first, tab([s[0] for s in segs]), tab([s[1] for s in segs]),
-                                   tab([s[2] for s in segs]), tab([s[3] for s in segs]), *lds, N, H, int(A), Ap,
-                                   tab([g[1] for g in groups]), tab([g[2] for g in groups]), tab([g[3] for g in groups]),
-                                   _stream()), "fbl_adapter_bwd_dw")
+                                   tab([s[2] for s in segs]), tab([s[3] for s in segs]), ldt(0), ldt(1), ldt(2), ldt(3),
+                                   N, H, int(A), Ap, tab([g[1] for g in groups]), tab([g[2] for g in groups]),
+                                   tab([g[3] for g in groups]), _stream()), "fbl_adapter_bwd_dw")
 
 
 # ------------------------------------------------------------------------------------------------ row ops
@@ -319,9 +324,10 @@ def ln_bwd(dout, t, stats, gamma, *, rowmask=None, p_drop=0.0, seed=0, out_dt=No
            dgamma=None, dbeta=None, dysum=None, ws=None):
     N, H = t.shape
     assert dout.is_contiguous() and t.is_contiguous()
+    ld_dyb = _rows2d(out_dy_bf16, "out_dy_bf16") if out_dy_bf16 is not None else 0
     _chk(load().fbl_ln_bwd(_p(dout), _p(rowmask), _p(t), _p(stats), _p(gamma), float(p_drop), int(seed), _p(out_dt),
-                           _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(dysum), _p(ws), N, H, _stream()),
-         "fbl_ln_bwd")
+                           _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(dysum), _p(ws), N, H, ld_dyb,
+                           _stream()), "fbl_ln_bwd")
 
 
 def im2col3(x_bf16, out_bf16, B, S, H):

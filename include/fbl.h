@@ -94,20 +94,21 @@ int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_b
 /* Weight and bias gradients of a GROUP of bottleneck adapters of one shape, accumulated (+=) by ONE launch:
  *     dWu[o][H,A] += sum_s dy_s^T . z_s      dWd[o][A,H] += sum_s dz_s^T . x_s      dbd[o][A] += sum_s colsum(dz_s)
  * over the segments s in [seg_first[o], seg_first[o+1]) of adapter o (one segment per execution of the adapter in the
- * forward pass; seg_first: HOST array of n_adapters + 1 ints, seg_first[0] = 0).  dy_s, x_s: bf16 [N,H] (row strides ld_dy,
- * ld_x); z_s = dropout(relu(down(x_s))), dz_s = grad of the bottleneck pre-activation: bf16 [N,Ap], Ap = A rounded up to 64
+ * forward pass; seg_first: HOST array of n_adapters + 1 ints, seg_first[0] = 0).  dy_s, x_s: bf16 [N,H] (row strides
+ * ld_dy[o], ld_x[o]: HOST arrays, one entry per adapter -- its segments share them; operands may be column slices of wider
+ * buffers); z_s = dropout(relu(down(x_s))), dz_s = grad of the bottleneck pre-activation: bf16 [N,Ap], Ap = A rounded up to 64
  * (<= 256), columns A..Ap-1 zero.  The pointer tables (dy_bf16 .. x_bf16: one entry per segment; dWu, dWd, dbd: one entry
  * per adapter, a table or an entry may be NULL) are HOST arrays of DEVICE pointers, read during the call.  Every output
  * tile has one writer that walks all rows: no workspace, deterministic; the more adapters per call, the better the chip is
- * filled (2 x ceil(H/64) workgroups per adapter).  Gradients are contiguous fp32.  ld_* and H multiples of 8.
+ * filled (2 x ceil(H/64) workgroups per adapter).  Gradients are contiguous fp32.  Strides and H multiples of 8.
  * (up.bias's gradient colsum(dy) comes out of fbl_ln_bwd's `dysum`.)
  * ref: autograd of model/adapter.py:38-42 (down, ReLU, dropout, up). */
 #define FBL_ADW_MAX_ADAPTERS 16
 #define FBL_ADW_MAX_SEGMENTS 24
 int fbl_adapter_bwd_dw(int n_adapters, const int32_t* seg_first, const void* const* dy_bf16, const void* const* z_bf16,
-                       const void* const* dz_bf16, const void* const* x_bf16, int64_t ld_dy, int64_t ld_z, int64_t ld_dz,
-                       int64_t ld_x, int N, int H, int A, int Ap, float* const* dWu, float* const* dWd, float* const* dbd,
-                       void* stream);
+                       const void* const* dz_bf16, const void* const* x_bf16, const int64_t* ld_dy, const int64_t* ld_z,
+                       const int64_t* ld_dz, const int64_t* ld_x, int N, int H, int A, int Ap, float* const* dWu,
+                       float* const* dWd, float* const* dbd, void* stream);
 
 /* out_f32[M,N] += sum_k A[k,m] * B[k,n]: both operands row-major bf16 ([K,M] and [K,N]), contraction over ROWS, so the
  * trainable-weight gradients dW = X^T . dY need no transposed copies in HBM.  Split-K with deterministic workspace fold
@@ -159,12 +160,13 @@ int fbl_ln_materialize(const float* t, const float* stats, const float* gamma, c
  *  out_dt fp32 [N,H]: grad wrt t (= grad of the residual branch).  out_dy_bf16/out_dy_f32: grad wrt y (dropout mask
  *  regenerated from seed), optional.  dgamma/dbeta [H] and dysum [H] (= column sums of dy: the bias gradient of the
  *  layer that produced y) are ACCUMULATED (+=) deterministically via `ws` (fbl_ln_bwd_ws_floats(H) floats); each may
- *  be NULL.
+ *  be NULL.  ld_dy_bf16: row stride of out_dy_bf16 in elements (0 = H; a multiple of 8): dy can land in the first H columns
+ *  of a wider operand buffer ([dy | dz] of the folded adapter backward).
  * ref: autograd of torch.nn.LayerNorm + XDropout.backward (model/deberta.py:185-190). */
 int64_t fbl_ln_bwd_ws_floats(int H);
 int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats, const float* gamma,
                float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16, float* out_dy_f32, float* dgamma,
-               float* dbeta, float* dysum, float* ws, int N, int H, void* stream);
+               float* dbeta, float* dysum, float* ws, int N, int H, int64_t ld_dy_bf16, void* stream);
 
 /* out[n, k*H + c] = x[b, s+k-1, c] (0 outside the sequence), n = b*S+s, k in {0,1,2}: im2col for the 3-tap conv.
  * ref: model/deberta.py:396-400 (Conv1d k=3 pad=1 over the sequence axis). */

@@ -151,16 +151,23 @@ def test_adapter_bwd_dw(L, N, H, A, nad):
     executed twice); strided wide operand; accumulation into pre-filled outputs; bit-reproducible; NULL outputs."""
     Ap = (A + 63) // 64 * 64
 
-    def seg(seed):
-        dyf = torch.zeros(N, H + 64, dtype=BF16, device=DEV)  # strided wide operand (a column slice of a wider buffer)
-        dyf[:, :H] = bf(rnd(N, H, seed=seed))
+    def seg(seed, folded):
+        # folded: dy and dz are column slices of ONE wider buffer ([dy | dz | pad], the folded backward operand);
+        # otherwise dy / x are slices of their own padded buffers -- row strides differ from adapter to adapter
+        if folded:
+            buf = torch.zeros(N, H + Ap + 64, dtype=BF16, device=DEV)
+            dy, dz = buf[:, :H], buf[:, H:H + Ap]
+        else:
+            dy = torch.zeros(N, H + 64, dtype=BF16, device=DEV)[:, :H]
+            dz = torch.zeros(N, Ap, dtype=BF16, device=DEV)
+        dy.copy_(bf(rnd(N, H, seed=seed)))
+        dz[:, :A] = bf(rnd(N, A, seed=seed + 3, scale=0.1))
         xf = torch.zeros(N, H + 64, dtype=BF16, device=DEV)
         xf[:, :H] = bf(rnd(N, H, seed=seed + 1))
         z = torch.zeros(N, Ap, dtype=BF16, device=DEV); z[:, :A] = torch.relu(bf(rnd(N, A, seed=seed + 2)))
-        dz = torch.zeros(N, Ap, dtype=BF16, device=DEV); dz[:, :A] = bf(rnd(N, A, seed=seed + 3, scale=0.1))
-        return dyf[:, :H], z, dz, xf[:, :H]
+        return dy, z, dz, xf[:, :H]
 
-    segs = [[seg(100 * o + 10 * k) for k in range(2 if o == 0 else 1)] for o in range(nad)]
+    segs = [[seg(100 * o + 10 * k, o % 2 == 1) for k in range(2 if o == 0 else 1)] for o in range(nad)]
     outs = []
     for _ in range(2):
         grp = [(segs[o], torch.full((H, A), 0.25, dtype=F32, device=DEV), torch.full((A, H), -0.5, dtype=F32, device=DEV),
@@ -249,6 +256,10 @@ def test_ln_fwd_bwd(L, H):
     close(dt, tt.grad, 1e-4, 1e-4, "dt")
     close(dys - 1.0, tt.grad.sum(0), 1e-4, 1e-3, "colsum(dy)")
     close(dyb, tt.grad, 1e-2, 1e-2, "dy bf16")
+    # dy into the first H columns of a wider operand buffer (the [dy | dz] operand of the folded adapter backward)
+    wide = torch.full((N, H + 192), 3.0, dtype=BF16, device=DEV)
+    L.ln_bwd(dout, t, st, g, rowmask=rowmask, out_dy_bf16=wide[:, :H], ws=L.ln_bwd_ws(H, DEV))
+    assert torch.equal(wide[:, :H], dyb) and (wide[:, H:] == 3.0).all()
     xh = (tt.detach() - tt.detach().mean(1, keepdim=True)) * st[:, 1:2]
     close(dg - dg0, (dout * rowmask[:, None] * xh).sum(0), 1e-4, 1e-3, "dgamma")
     close(db - db0, (dout * rowmask[:, None]).sum(0), 1e-4, 1e-3, "dbeta")
