@@ -389,8 +389,8 @@ def spawn_ranks(n: int) -> int:
 
 def measure_gemm_roofline(L, step_fn):
     """Instrumented replay: HIP events (torch's current stream == the launch stream) around every launch of the GEMM family
-    of one step (fbl_gemm_bf16_nt, fbl_dense_adapter_down_fwd, fbl_adapter_down_fwd, fbl_gemm_bf16_tn_acc), on whichever
-    stream the engine issues it."""
+    of one step (fbl_gemm_bf16_nt, fbl_dense_adapter_down_fwd, fbl_adapter_down_fwd, fbl_gemm_bf16_tn_acc,
+    fbl_adapter_bwd_dw), on whichever stream the engine issues it."""
     import frozenbilm_amd.lib as lib
 
     recs = []
@@ -411,7 +411,7 @@ def measure_gemm_roofline(L, step_fn):
         recs.append((s, e, 2.0 * M * N * K * nb, (M, N, K, nb), big))
 
     # the other entry points of the GEMM family: merged dense + adapter-down, stand-alone adapter-down, dW (A^T.B)
-    orig_dad, orig_ad, orig_tn = lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc
+    orig_dad, orig_ad, orig_tn, orig_dw = lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc, lib.adapter_bwd_dw
 
     def bracket(fn, shape_of, big_ok=False):
         def wrapped(*a, **kw):
@@ -428,6 +428,12 @@ def measure_gemm_roofline(L, step_fn):
     lib.adapter_down_fwd = bracket(orig_ad, lambda x, wd, b, z, A=None, **kw: (x.shape[0], A or wd.shape[0], x.shape[1]))
     lib.gemm_tn_acc = bracket(orig_tn, lambda A_, B_, o, ws, M=None, N=None, K=None, **kw:
                               (M or A_.shape[1], N or B_.shape[1], K or min(A_.shape[0], B_.shape[0])))
+
+    def dw_shape(groups, A):  # grouped adapter gradients: two [H x A] products over N rows per segment, as one "batch"
+        dy = groups[0][0][0][0]
+        return (dy.shape[1], A, dy.shape[0] * 2 * sum(len(g[0]) for g in groups))
+
+    lib.adapter_bwd_dw = bracket(orig_dw, dw_shape)
     try:
         step_fn()
         recs.clear()
@@ -435,6 +441,7 @@ def measure_gemm_roofline(L, step_fn):
         torch.cuda.synchronize()
     finally:
         lib.gemm, lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc = orig, orig_dad, orig_ad, orig_tn
+        lib.adapter_bwd_dw = orig_dw
     def summary(rs):
         ms = sum(s.elapsed_time(e) for s, e, *_ in rs)
         fl = sum(r[2] for r in rs)
@@ -474,7 +481,7 @@ def measure_gemm_roofline(L, step_fn):
             "avg_launch_us": dom_ms * 1e3 / max(len(dom), 1), "kernel_ms_per_step": dom_ms,
             "algorithmic_tflops_per_step": dom_fl / 1e12,
             "family": {"what": "every launch of the GEMM family (gemm8_kernel, gemm_bf16_nt_kernel incl. split-K / batched "
-                               "position-table products, gemm_bf16_tn_kernel dW)", "achieved": ach,
+                               "position-table products, the grouped adapter-gradient kernel adapter_dw_kernel)", "achieved": ach,
                        "frac": ach / PEAK_BF16_TFLOPS, "launches_per_step": len(recs), "gemm_ms_per_step": tot_ms,
                        "hbm_gb_per_step_committed": fam_gb},
             "gemm_ms_per_step": tot_ms, "executed_gemm_tflops_per_step": tot_fl / 1e12,

@@ -801,13 +801,13 @@ class Engine:
         return dx
 
     def _dw_flush(self, run, red=None, force=False):
-        """Launch the parked adapter-gradient products (see _adapter_bwd) once `dw_group` of them are pending -- one
+        """Launch the parked adapter-gradient products (see _adapter_bwd) once `dw_group` distinct adapters are pending -- one
         launch of 2 x H/64 workgroups per adapter; 16 adapters = 768 workgroups = three per CU, all resident -- or all of
         them (force), and only then tell the gradient reducer about the stages whose buckets they complete.  An adapter
         appears once per launch: the second execution of the last layer (enhanced mask decoder) waits for the next one,
         so that no launch has a double-length tile."""
         pend = run.dw_pending
-        while pend and (force or len(pend) >= self.dw_group):
+        while pend and (force or len({rec[1] for rec in pend}) >= self.dw_group):
             take, names, rest = {}, set(), []
             for rec in pend:
                 A, nm, seg, _ = rec

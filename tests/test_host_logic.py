@@ -133,3 +133,47 @@ def test_oracle_xlarge_golden(golden):
     assert abs(lg.double().sum().item() - g["logits_sum"].item()) < 1e-3 * g["logits_abs_sum"].item() * 1e-3 + 5.0
     assert torch.equal(lg.argmax(-1), g["argmax"])
     assert torch.equal(lg.topk(5, -1).indices[:, ::7], g["top5"])
+
+
+def test_adapter_gradient_grouping_policy(monkeypatch):
+    """Engine._dw_flush (host logic, no GPU): parked adapter-gradient products leave in launches of `dw_group` distinct
+    adapters, an adapter executed twice (the last layer, enhanced mask decoder) is split over two launches, and the gradient
+    reducer hears about a stage only when every product parked before the stage's end has been launched -- in stage order."""
+    from frozenbilm_amd import engine as E
+
+    launches = []
+    monkeypatch.setattr(E.L, "adapter_bwd_dw", lambda groups, A: launches.append([g[1] for g in groups]))
+    nL = 8
+    names = lambda li: [f"layer.{li}.a1", f"layer.{li}.a2"]
+    G = {n + sfx: n for li in range(nL) for n in names(li) for sfx in (".up.weight", ".down.weight", ".down.bias")}
+    eng = types.SimpleNamespace(dw_group=6, G=G)
+    run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0)
+    ready = []
+    red = types.SimpleNamespace(ready=ready.append)
+
+    def park(li):
+        for n in names(li):
+            run.dw_pending.append((192, n, (None, None, None, None), run.dw_count))
+            run.dw_count += 1
+
+    def stage_done(key):
+        run.dw_ready_keys.append((key, run.dw_count))
+        E.Engine._dw_flush(eng, run, red)
+
+    stage_done("head")
+    assert ready == ["head"] and not launches  # nothing parked yet: final at once
+    park(nL - 1)
+    park(nL - 1)  # second execution of the last layer
+    stage_done(f"layer{nL - 1}")
+    for li in range(nL - 2, -1, -1):
+        park(li)
+        stage_done(f"layer{li}")
+        if li == 5:  # six distinct adapters pending: the first launch leaves, the repeated pair stays behind ...
+            assert launches == [names(7) + names(6) + names(5)] and ready == ["head"]  # ... and with it layer 7's bucket
+    E.Engine._dw_flush(eng, run, red, force=True)
+    assert not run.dw_pending and not run.dw_ready_keys
+    assert all(len(set(l)) == len(l) <= 6 for l in launches)  # an adapter at most once per launch
+    flat = [n for l in launches for n in l]
+    assert sorted(flat) == sorted(names(nL - 1) * 2 + [n for li in range(nL - 1) for n in names(li)])
+    assert launches[1][:2] == names(7)  # the deferred pair leads the next launch
+    assert ready == ["head"] + [f"layer{li}" for li in range(nL - 1, -1, -1)]
