@@ -79,7 +79,9 @@ def pos_table_grads(eng, st, ws):
     G1T, G2T, QT, KT = st["G1T"], st["G2T"], st["QT"], st["KT"]
     dpos = torch.zeros(span2, 2 * H, dtype=F32, device=eng.dev)
     Kc = B * Sp
-    sk = max(2, min(16, Kc // 1024))
+    # split count: 5 at the bench shape (K = B*Sp = 10240).  Measured step time for 2 / 3 / 4 / 5 / 10 slices: 49.20 /
+    # 48.90 / 48.89 / 48.56-48.71 / 48.88-48.95 ms (same box) -- half the partial-sum traffic of 10, still short workgroups
+    sk = max(2, min(16, Kc // 2048))
     o_pk = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), H + rmin * 2 * H)
     o_pq = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), rmin * 2 * H)
     kblk = rcnt * 32  # elements between consecutive 32-wide k blocks of G^T
