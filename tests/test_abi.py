@@ -88,3 +88,31 @@ def test_gemm_plan_host_query(libpath):
                 (8512, 1536, 1600)]:
         assert L.gemm_plan(*shp) == 2, shp
     assert L.gemm_plan(8512, 6144, 1536, batch=2) == 2 and L.gemm_plan(8512, 6144, 1536, splitk=4) == 2
+
+
+def test_adapter_bwd_dw_rejects_bad_arguments_on_the_host(libpath):
+    """fbl_adapter_bwd_dw validates its tables before any launch (pure host logic, no GPU needed): group / segment limits,
+    the bottleneck padding contract, stride alignment and ranges (include/fbl.h)."""
+    from frozenbilm_amd import lib as L
+
+    h = L.load(libpath)
+    P = ctypes.c_void_p
+    one = (P * 24)(*[0x1000] * 24)  # never dereferenced: every call below fails validation first
+
+    def call(n=1, first=(0, 1), N=128, H=128, A=64, Ap=64, ld=(128, 64, 64, 128), dy=one, first_null=False):
+        sf = None if first_null else (ctypes.c_int32 * len(first))(*first)
+        lds = [(ctypes.c_int64 * max(n, 1))(*[v] * max(n, 1)) for v in ld]
+        return h.fbl_adapter_bwd_dw(n, sf, dy, one, one, one, *lds, N, H, A, Ap, None, None, None, None)
+
+    assert call(n=0) == 0 and call(N=0) == 0  # nothing to do
+    assert call(n=17, first=tuple(range(18))) < 0  # more adapters than FBL_ADW_MAX_ADAPTERS
+    assert call(first=(1, 2)) < 0          # seg_first[0] must be 0
+    assert call(first=(0, 25)) < 0         # more segments than FBL_ADW_MAX_SEGMENTS
+    assert call(first=(0, 0)) < 0          # an empty group
+    assert call(first_null=True) < 0
+    assert call(Ap=96) < 0 and call(Ap=320, A=300) < 0 and call(A=65, Ap=64) < 0  # Ap = A rounded up to 64, <= 256
+    assert call(H=100) < 0                 # H % 8
+    assert call(ld=(132, 64, 64, 128)) < 0  # stride alignment
+    assert call(ld=(64, 64, 64, 128)) < 0   # ld_dy < H
+    assert call(ld=(128, 32, 64, 128)) < 0  # ld_z < Ap
+    assert call(dy=None) < 0
