@@ -97,6 +97,7 @@ class Engine:
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
+        self.pos_on_main = os.environ.get("FBL_POS_MAIN", "0") == "1"  # A/B switch: position-table gradient chain on the main stream (+2.5 ms)
         self.fold_dx = os.environ.get("FBL_NO_FOLD_DX", "0") != "1"  # A/B switch: adapter dx folded into the dense dX GEMM
         self.dw_on_side = os.environ.get("FBL_DW_SIDE", "0") == "1"  # A/B switch: generic dW route on the side stream
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(os.environ.get("FBL_DW_GROUP", "16"))))  # adapter gradient products per launch (<= 16)
@@ -895,7 +896,7 @@ class Engine:
             else:
                 L.gemm(dpb, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
 
-        if self.use_side_stream and os.environ.get("FBL_POS_MAIN") != "1":
+        if self.use_side_stream and not self.pos_on_main:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 work(self.side_ws)
