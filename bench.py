@@ -389,8 +389,8 @@ def spawn_ranks(n: int) -> int:
 
 def measure_gemm_roofline(L, step_fn):
     """Instrumented replay: HIP events (torch's current stream == the launch stream) around every launch of the GEMM family
-    of one step (fbl_gemm_bf16_nt, fbl_dense_adapter_down_fwd, fbl_adapter_down_fwd, fbl_gemm_bf16_tn_acc,
-    fbl_adapter_bwd_dw), on whichever stream the engine issues it."""
+    of one step (fbl_gemm_bf16_nt, fbl_dense_adapter_down_fwd, fbl_adapter_down_fwd, fbl_adapter_up_resid_fwd,
+    fbl_gemm_bf16_tn_acc, fbl_adapter_bwd_dw), on whichever stream the engine issues it."""
     import frozenbilm_amd.lib as lib
 
     recs = []
@@ -412,6 +412,7 @@ def measure_gemm_roofline(L, step_fn):
 
     # the other entry points of the GEMM family: merged dense + adapter-down, stand-alone adapter-down, dW (A^T.B)
     orig_dad, orig_ad, orig_tn, orig_dw = lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc, lib.adapter_bwd_dw
+    orig_up = lib.adapter_up_resid_fwd
 
     def bracket(fn, shape_of, big_ok=False):
         def wrapped(*a, **kw):
@@ -426,6 +427,7 @@ def measure_gemm_roofline(L, step_fn):
     lib.gemm = timed
     lib.dense_adapter_down_fwd = bracket(orig_dad, lambda x, wm, *a, **kw: (x.shape[0], wm.shape[0], x.shape[1]), big_ok=True)
     lib.adapter_down_fwd = bracket(orig_ad, lambda x, wd, b, z, A=None, **kw: (x.shape[0], A or wd.shape[0], x.shape[1]))
+    lib.adapter_up_resid_fwd = bracket(orig_up, lambda z, wu, bu, x, t, A=None, **kw: (x.shape[0], x.shape[1], A or wu.shape[1]))
     lib.gemm_tn_acc = bracket(orig_tn, lambda A_, B_, o, ws, M=None, N=None, K=None, **kw:
                               (M or A_.shape[1], N or B_.shape[1], K or min(A_.shape[0], B_.shape[0])))
 
@@ -441,7 +443,8 @@ def measure_gemm_roofline(L, step_fn):
         torch.cuda.synchronize()
     finally:
         lib.gemm, lib.dense_adapter_down_fwd, lib.adapter_down_fwd, lib.gemm_tn_acc = orig, orig_dad, orig_ad, orig_tn
-        lib.adapter_bwd_dw = orig_dw
+        lib.adapter_bwd_dw, lib.adapter_up_resid_fwd = orig_dw, orig_up
+
     def summary(rs):
         ms = sum(s.elapsed_time(e) for s, e, *_ in rs)
         fl = sum(r[2] for r in rs)

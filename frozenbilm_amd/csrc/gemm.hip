@@ -398,6 +398,11 @@ static bool fork_join_events(hipStream_t s, hipStream_t aux, hipEvent_t* fork, h
   return true;
 }
 
+// residual operand of the adapter-tail epilogue (fbl_adapter_up_resid_fwd)
+struct TailArgs {
+  const float* r_t; int64_t ld_r; const float* r_stats; const float* r_gamma; const float* r_beta; const int32_t* r_rowmask;
+};
+
 // p_drop > 0 (ReLU epilogue only): dropout of the activated output, element (m, n) keyed by (drop_seed, m*ldc + n)
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                         const float* bias, const float* rowscale, float alpha, int act, int aux_kind,
@@ -406,8 +411,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                         int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
                         float p_drop, uint64_t drop_seed, void* stream, int seg_n = 0, void* seg_out = nullptr,
-                        int64_t seg_ld = 0, int64_t drop_row0 = 0, void* aux_stream = nullptr) {
+                        int64_t seg_ld = 0, int64_t drop_row0 = 0, void* aux_stream = nullptr,
+                        const TailArgs* tail = nullptr) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  if ((aux_kind == FBL_AUX_ADAPTER_TAIL) != (tail != nullptr)) return FBL_ERR_ARG;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
   if ((lda % 8) != 0 || (ldb % 8) != 0) return FBL_ERR_ALIGN;  // 16-byte operand rows
   if (splitk < 1) splitk = 1;
@@ -439,6 +446,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
   g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
   g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
+  g.r_t = nullptr; g.ld_r = 0; g.r_stats = nullptr; g.r_gamma = nullptr; g.r_beta = nullptr; g.r_rowmask = nullptr;
+  if (tail) {
+    if (accumulate || batch != 1 || seg_n > 0 || !out_f32 || out_bf16 || out_pre_bf16 || act != FBL_ACT_NONE || rowscale ||
+        !aux || !tail->r_t || (N & 3) || (ldc & 3) || (ld_aux & 3) || (tail->ld_r & 3) ||
+        (tail->r_stats && (!tail->r_gamma || !tail->r_beta)))
+      return FBL_ERR_ARG;
+    g.r_t = tail->r_t; g.ld_r = tail->ld_r; g.r_stats = tail->r_stats; g.r_gamma = tail->r_gamma; g.r_beta = tail->r_beta;
+    g.r_rowmask = tail->r_rowmask;
+    g.drop_ld = N;  // keys of fbl_ln_fwd: (seed, m*H + n)
+  }
   if (seg_n > 0) {
     // The epilogue branches per LANE on "column >= seg_n" but stages accumulators through per-WAVE LDS patches that all 64
     // lanes fill: the segment boundary must not cut a wave's column range.  A wave of the 2-stage kernels owns 64
@@ -448,14 +465,14 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     g.drop_ld = seg_ld;
   }
   if (p_drop > 0.f) {
-    if ((act != FBL_ACT_RELU && seg_n <= 0) || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
+    if ((act != FBL_ACT_RELU && seg_n <= 0 && !tail) || p_drop >= 1.f || batch != 1) return FBL_ERR_ARG;
     g.drop_thresh = fbl_drop_thresh(p_drop);
     g.drop_inv_keep = 1.f / (1.f - p_drop);
   }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = FBL_ENV_INT("FBL_GEMM_SMALL", 0);
-  const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0) && (seg_n <= 0 || (seg_n & 255) == 0) &&
+  const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0 || tail) && (seg_n <= 0 || (seg_n & 255) == 0) &&
                    big_tile_shape(M, N, batch);
   // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
   // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
@@ -477,7 +494,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       g.skew_ticks = (int)(tile_us * 100.0 / 5.0 * 0.01 * skew_mode);  // four groups, (1..4) x skew_mode/5 % of a tile late
     }
   }
-  if (big && splitk_ws_floats >= 0 && !skewed_single_launch) {  // (negative values mark the two halves of an already split launch)
+  if (big && splitk_ws_floats >= 0 && !skewed_single_launch && !tail) {  // (negative values mark the two halves of an already split launch)
     // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
     // round would be mostly empty, give the big tiles only as many M rows as fill whole rounds and run the remaining
     // rows with the 128x128 configuration (2 workgroups/CU, 1/4 of the work per tile) right behind.
@@ -653,6 +670,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADD_BF16, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16, false);
   else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_POS_BF16) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_MUL_POS_BF16, false);
+  else if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADAPTER_TAIL) FBL_GEMM_LAUNCH(FBL_ACT_NONE, FBL_AUX_ADAPTER_TAIL, false);
   else return FBL_ERR_ARG;
 #undef FBL_GEMM_LAUNCH
 #undef FBL_GEMM_LAUNCH_NW
@@ -684,6 +702,7 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                                 int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
                                 void* stream, void* aux_stream) {
+  if (aux_kind == FBL_AUX_ADAPTER_TAIL) return FBL_ERR_ARG;  // (has its own entry point: fbl_adapter_up_resid_fwd)
   return gemm_nt_impl(A, lda, B, ldb, M, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32, out_bf16,
                       out_pre_bf16, ldc, batch, strideA, strideB, strideC, strideAux, strideBias, splitk, splitk_ws,
                       splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream, 0, nullptr, 0, 0, aux_stream);
@@ -713,6 +732,20 @@ extern "C" int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const
   return gemm_nt_impl(x_bf16, ldx, wm_bf16, ldw, M, N1 + A, K, bias_m, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_NONE, nullptr, 0,
                       y_f32, y_bf16, nullptr, ldy, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, N1,
                       z_bf16, ldz, 0, aux_stream);
+}
+
+extern "C" int fbl_adapter_up_resid_fwd(const void* z_bf16, int64_t ldz, const void* wu_bf16, int64_t ldw, int M, int H, int A,
+                                        const float* bias_u, const void* x_bf16, int64_t ldx, float p_drop, uint64_t seed,
+                                        const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
+                                        const float* r_beta, const int32_t* r_rowmask, float* out_t, int64_t ldt,
+                                        void* stream) {
+  if (!z_bf16 || !wu_bf16 || !x_bf16 || !r_t || !out_t) return FBL_ERR_ARG;
+  if (p_drop < 0.f || p_drop >= 1.f) return FBL_ERR_ARG;
+  if (ldx % 8) return FBL_ERR_ALIGN;
+  const TailArgs tail{r_t, ld_r, r_stats, r_gamma, r_beta, r_rowmask};
+  return gemm_nt_impl(z_bf16, ldz, wu_bf16, ldw, M, H, A, bias_u, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_ADAPTER_TAIL, x_bf16, ldx,
+                      out_t, nullptr, nullptr, ldt, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, 0,
+                      nullptr, 0, 0, nullptr, &tail);
 }
 
 extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     return;
   }
   const int ec = (lane & 15) * 4;
-  gemm_epilogue<ACT, AUX, false, 8>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
+  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
                                     0, 0, short_rows ? 48 : 64);
 }
 
@@ -276,15 +276,21 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     }                                                                                                           \
     hipLaunchKernelGGL(kfn, grid, dim3(512), SMEM8_BYTES, stream, g);                                           \
   } while (0)
-  if constexpr (ACT == FBL_ACT_NONE && AUX == FBL_AUX_NONE && !R224) {  // the experiment variants exist for the plain epilogue only
+#ifdef FBL_DEBUG_SWITCHES
+  if constexpr ((ACT == FBL_ACT_NONE || ACT == FBL_ACT_GELU_GRAD) && AUX == FBL_AUX_NONE && !R224) {  // experiment variants
     if (var == 0) FBL_G8_LAUNCH(0);
     else if (var == 1) FBL_G8_LAUNCH(1);
     else if (var == 2) FBL_G8_LAUNCH(2);
     else if (var == 7) FBL_G8_LAUNCH(7);
+    else if (var == 11) FBL_G8_LAUNCH(11);  // no global stores
+    else if (var == 19) FBL_G8_LAUNCH(19);  // stores alias 256 rows
     else FBL_G8_LAUNCH(3);
   } else {
     FBL_G8_LAUNCH(3);
   }
+#else
+  FBL_G8_LAUNCH(3);
+#endif
 #undef FBL_G8_LAUNCH
   FBL_CHECK_LAUNCH();
   return 0;

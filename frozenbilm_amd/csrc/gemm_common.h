@@ -53,6 +53,15 @@ struct GemmArgs {
   int seg_n;
   bf16* seg_out;
   long seg_ld;
+  // Adapter tail (FBL_AUX_ADAPTER_TAIL, fbl_adapter_up_resid_fwd): out_f32 = dropout(alpha*acc + bias + aux_bf16) + resid, the
+  // residual either plain (r_stats == null: r_t[m,n]) or in LayerNorm-normalised form ((r_t - mean[m]) * rstd[m] * r_gamma[n]
+  // + r_beta[n]) * r_rowmask[m]; dropout = drop_* keyed by (m + drop_row0) * drop_ld + n like fbl_ln_fwd
+  const float* r_t;
+  long ld_r;
+  const float* r_stats;
+  const float* r_gamma;
+  const float* r_beta;
+  const int32_t* r_rowmask;
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
@@ -141,12 +150,101 @@ __device__ __forceinline__ void gemm_epilogue_seg(const GemmArgs& g, char* smem,
   }
 }
 
+
+// Epilogue of the adapter tail (GemmArgs::r_t).  The per-row LayerNorm statistics of the residual travel through the four
+// padding floats of each staged row (columns 64..67 of the wave-private tile), so they cost no registers in the row loop.
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_tail(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
+                                                int m_first, int m_slab_stride, int n4, int slab_rows) {
+  constexpr int LDW = 68;
+  float* stage = (float*)smem + wave * (64 * LDW);
+  const int frow = lane & 15, fg = lane >> 4;
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  const bool live = n4 + 3 < g.N;       // (N % 4 == 0 is checked on the host)
+  const int nc = live ? n4 : 0;         // loads of dead lanes stay in bounds
+  float bv[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+    const f32x4 t = *(const f32x4*)(g.bias + nc);
+    bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+  }
+  const bool normed = g.r_stats != nullptr;
+  if (normed) {
+    const f32x4 t = *(const f32x4*)(g.r_gamma + nc), u = *(const f32x4*)(g.r_beta + nc);
+    gg[0] = t[0]; gg[1] = t[1]; gg[2] = t[2]; gg[3] = t[3];
+    bb[0] = u[0]; bb[1] = u[1]; bb[2] = u[2]; bb[3] = u[3];
+  }
+#pragma unroll
+  for (int half = 0; half < (MI + 3) / 4; ++half) {
+    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;
+    const int mslab = m_first + half * m_slab_stride;
+    bf16x4 xa[16];
+    f32x4 ra[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (it < cnt * 4) {
+        const long m = min(mslab + it * 4 + er, g.M - 1);
+        xa[it] = *(const bf16x4*)((const bf16*)g.aux + m * g.ld_aux + nc);
+        ra[it] = *(const f32x4*)(g.r_t + m * g.ld_r + nc);
+      }
+    }
+    float mean = 0.f, rstd = 1.f, rm = 1.f;  // statistics of row mslab + lane
+    if (normed) {
+      const long m = min(mslab + lane, g.M - 1);
+      const f32x2 st = *(const f32x2*)(g.r_stats + 2 * m);
+      mean = st[0];
+      rstd = st[1];
+      if (g.r_rowmask) rm = (float)g.r_rowmask[m];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      if (half * 4 + mi < MI) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
+      }
+    *(f32x4*)(stage + lane * LDW + 64) = (f32x4){mean, rstd, rm, 0.f};
+    // every global load of the slab has landed before its first store (see gemm_epilogue)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      asm volatile("" : "+v"(xa[it]));
+      asm volatile("" : "+v"(ra[it]));
+    }
+    if (live) {
+      const long er_c = (long)(mslab + er) * g.ldc + n4;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        if (it >= cnt * 4) break;
+        const int row = it * 4 + er;
+        const int m = mslab + row;
+        if (m >= g.M || row >= slab_rows) continue;
+        const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
+        const f32x4 st = *(const f32x4*)(stage + row * LDW + 64);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = a4[r] * g.alpha + bv[r] + bf2f(xa[it][r]);
+          if (g.drop_thresh)
+            v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
+          v[r] += normed ? ((ra[it][r] - st[0]) * st[1] * gg[r] + bb[r]) * st[2] : ra[it][r];
+        }
+        *(f32x4*)(g.out_f32 + er_c + (long)(it * 4) * g.ldc) = (f32x4){v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+}
+
 //   slab_rows (<= 64): rows of a slab that belong to this wave (the 224-row configuration of the 8-phase kernel gives
 //   its second wave row 48 of them); rows beyond it are not stored.
-template <int ACT, int AUX, bool SPLITK, int MI>
+// DBG (measurement builds only): bit 0 = everything but the global stores (values kept alive), bit 1 = the stores of all
+// tile rows alias the first 256 rows of C (the output stays L2-resident: store issue without HBM write traffic)
+template <int ACT, int AUX, bool SPLITK, int MI, int DBG = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
                                               int m_first, int m_slab_stride, int n4, int batch, int ks,
                                               int slab_rows = 64) {
+  if constexpr (AUX == FBL_AUX_ADAPTER_TAIL) {
+    gemm_epilogue_tail<MI>(g, smem, wave, lane, acc, m_first, m_slab_stride, n4, slab_rows);
+    return;
+  }
   if (!SPLITK && g.seg_n > 0 && n4 >= g.seg_n) {  // (uniform per workgroup: seg_n is a multiple of the tile width)
     gemm_epilogue_seg<MI>(g, smem, wave, lane, acc, m_first, m_slab_stride, n4, slab_rows);
     return;
@@ -214,7 +312,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
     }
     if (n4 < g.N) {
     // element offsets of this lane's first row of the slab; the per-iteration part (4*it rows) is wave-uniform
-    const long er_c = cbase + (long)(mslab + er) * g.ldc + n4;
+    const long er_c = cbase + (long)((DBG & 2) ? ((mslab + er) & 255) : (mslab + er)) * g.ldc + n4;
     const long er_x = xbase + (long)(mslab + er) * g.ld_aux + n4;
     // (two copies of the row loop, selected by the wave-uniform aux_fast: the slow path loads aux inside the loop, and a
     //  join of "maybe a load is pending" with the fast path would put a vmcnt(0) into every iteration of both)
@@ -279,7 +377,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
         }
       }
       const long co = er_c + (long)(it * 4) * g.ldc;
-      if (full && vec_ok) {
+      if (DBG & 1) {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]), "v"(co));
+      } else if (full && vec_ok) {
         if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
         if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         if (g.out_pre) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};

@@ -100,6 +100,10 @@ class Engine:
         self.pos_on_main = os.environ.get("FBL_POS_MAIN", "0") == "1"  # A/B switch: position-table gradient chain on the main stream (+2.5 ms)
         self.fold_dx = os.environ.get("FBL_NO_FOLD_DX", "0") != "1"  # A/B switch: adapter dx folded into the dense dX GEMM
         self.dw_on_side = os.environ.get("FBL_DW_SIDE", "0") == "1"  # A/B switch: generic dW route on the side stream
+        # adapter up-projection + block dropout + residual as ONE epilogue that writes the LayerNorm's pre-norm tensor
+        # (fbl_adapter_up_resid_fwd); FBL_NO_TAIL=1 = the separate up GEMM (fp32 y) + fbl_ln_fwd (A/B switch)
+        self.fuse_tail = os.environ.get("FBL_NO_TAIL", "0") != "1"
+        L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(os.environ.get("FBL_DW_GROUP", "16"))))  # adapter gradient products per launch (<= 16)
 
     # ------------------------------------------------------------------ parameter plumbing
@@ -528,6 +532,36 @@ class Engine:
             y, z, seed = self._adapter_fwd(run, ent, o32, ob, N)
         return y, ob, z, seed
 
+    def _dense_adapter_ln(self, run, li, x_bf16, W, wkey, bkey, ent, A, merged, N, ln_name, resid: Stream, tail=0):
+        """dense -> adapter -> dropout -> LayerNorm(. + resid)  (model/deberta.py:254-260 / 328-334).  Returns (output
+        Stream, dense output bf16, z, adapter seed, LayerNorm-dropout seed).  With a merged adapter site the block is three
+        launches -- merged dense + down-projection GEMM (bf16 y, z), up-projection GEMM whose epilogue adds the adapter
+        input, applies the block's dropout and adds the residual (writes the pre-norm tensor t once), LayerNorm statistics
+        + bf16 operand -- and neither the fp32 dense output nor the fp32 adapter output exist in HBM."""
+        H, dev = self.H, self.dev
+        if not (self.fuse_tail and ent is not None and merged and ent["Ap"] == A):
+            y, ob, z, seed_ad = self._dense_adapter(run, li, x_bf16, W, wkey, bkey, ent, A, merged, N)
+            out, seed_ln = self._ln(run, ln_name, y=y, resid=resid, N=N, p_drop=run.p_hid, tail=tail)
+            return out, ob, z, seed_ad, seed_ln
+        ev = getattr(self, "_compose_ev", None)
+        if ev is not None:  # the composed rows of this layer must be there (layer 0: first event, others: second)
+            torch.cuda.current_stream().wait_event(ev[0] if li == 0 else ev[1])
+        ob = torch.empty(N, H, dtype=BF16, device=dev)
+        z = torch.empty(N, A, dtype=BF16, device=dev)
+        seed_ad = run.next_seed() if run.p_ad > 0 else 0
+        L.dense_adapter_down_fwd(x_bf16, W[wkey + "M"], W[bkey + "M"], H, z, y_bf16=ob, p_drop=run.p_ad, seed=seed_ad)
+        g, b = self.P[ln_name + ".weight"], self.P[ln_name + ".bias"]
+        t = torch.empty(N, H, dtype=F32, device=dev)
+        stats = torch.empty(N, 2, dtype=F32, device=dev)
+        full = torch.empty(N + tail, H, dtype=BF16, device=dev)
+        seed_ln = run.next_seed() if run.p_hid > 0 else 0
+        r_norm = resid.norm.as_args() if resid.norm is not None else None
+        L.adapter_up_resid_fwd(z, ent["up"], ent["bu"], ob, t, A=A, p_drop=run.p_hid, seed=seed_ln,
+                               r_plain=resid.plain if r_norm is None else None, r_norm=r_norm)
+        L.ln_fwd(y=t, gamma=g, beta=b, eps=self.cfg.layer_norm_eps, out_stats=stats, out_bf16=full[:N], N=N, H=H)
+        return (Stream(bf16=full[:N], norm=NormRef(t, stats, g, b, None), full=full if tail else None), ob, z, seed_ad,
+                seed_ln)
+
     def _layer_fwd(self, run, li: int, kv: Stream, q: Optional[Stream], Rb: torch.Tensor):
         """One execution of encoder layer ``li`` (model/deberta.py:351-375); q != None is the EMD form where the
         query stream (and the attention residual, :290-292) differs from the key/value stream."""
@@ -566,18 +600,18 @@ class Engine:
                           seed=sv.seed_att, klen=run.klen, border=run.border, lin=self.lin_span)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
         ad = self.ad[li]
-        y1, ob, z1, sv.seed_ad1 = self._dense_adapter(run, li, ctx, W, "Wo", "bo", ad.get("a1"), self.A1, self.merge1, N)
         p = f"deberta.encoder.layer.{li}"
-        a, sv.seed_ln1 = self._ln(run, p + ".attention.output.LayerNorm", y=y1, resid=(q if q is not None else kv), N=N,
-                                  p_drop=run.p_hid)
+        a, ob, z1, sv.seed_ad1, sv.seed_ln1 = self._dense_adapter_ln(
+            run, li, ctx, W, "Wo", "bo", ad.get("a1"), self.A1, self.merge1, N, p + ".attention.output.LayerNorm",
+            resid=(q if q is not None else kv))
         # FFN: gelu(dense) -> dense -> adapter -> dropout -> LN(. + a)          (:310-313, :328-334)
         h = torch.empty(N, I, dtype=BF16, device=dev)
         hpre = torch.empty(N, I, dtype=BF16, device=dev) if run.save else None
         # training: the epilogue stores gelu'(pre) (bf16) next to gelu(pre) so the backward epilogue is a plain multiply
         L.gemm(a.bf16, W["Wi"], bias=W["bi"], act=L.ACT_GELU_GRAD if run.save else L.ACT_GELU, out_bf16=h, out_pre=hpre)
-        y2, fb, z2, sv.seed_ad2 = self._dense_adapter(run, li, h, W, "Wd", "bd", ad.get("a2"), self.A2, self.merge2, N)
-        out, sv.seed_ln2 = self._ln(run, p + ".output.LayerNorm", y=y2, resid=Stream(bf16=a.bf16, norm=a.norm), N=N,
-                                    p_drop=run.p_hid, tail=self.span2)
+        out, fb, z2, sv.seed_ad2, sv.seed_ln2 = self._dense_adapter_ln(
+            run, li, h, W, "Wd", "bd", ad.get("a2"), self.A2, self.merge2, N, p + ".output.LayerNorm",
+            resid=Stream(bf16=a.bf16, norm=a.norm), tail=self.span2)
         if run.save:
             sv.qkv, sv.pqk, sv.ctx, sv.lse = qkv[:N], qkv[N:, : 2 * H], ctx, lse
             sv.ob, sv.z1, sv.ln1 = ob, z1, a.norm

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 3  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -27,6 +28,8 @@ SIGNATURES = {
                               _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp, _vp]),
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp]),
+    "fbl_adapter_up_resid_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp, _vp, _vp,
+                                      _vp, _l, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_adapter_bwd_dw": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -84,6 +87,10 @@ def load(path: Optional[str] = None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    ver = lib.fbl_abi_version()
+    if ver != ABI_VERSION:  # same symbol names, different argument lists: calling through would shift arguments silently
+        raise RuntimeError(f"{p} has ABI version {ver}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(python -m frozenbilm_amd.build --force)")
     if path is None:
         _LIB = lib
     return lib
@@ -98,10 +105,18 @@ def _stream():
 
 
 # The caller-provided aux stream of the two GEMM entry points that can use one (include/fbl.h).  The library owns no
-# stream: the engine creates one per device and registers it here; the bindings pass it only when the launch goes to the
-# stream it was registered for (its device's current stream at registration: the training stream) and never while that
-# would make a launch wait on itself.
+# stream: the engine creates one per device and registers it here.  The bindings pass it for launches on any stream of
+# that device (also a capturing one: the fork / join lands in the capture) EXCEPT the aux stream itself and the streams
+# listed in _NO_AUX -- the engine's side stream: its GEMMs must not fork into the in-order aux stream the main stream's
+# GEMMs use (that would make side work wait for main-stream remainder tiles and, under capture, pull it into the graph).
 _AUX = {}
+_NO_AUX = set()
+
+
+def exclude_from_aux(stream: "torch.cuda.Stream"):
+    """launches on `stream` never get the aux stream (see above)"""
+    _NO_AUX.add(stream.cuda_stream)
+
 
 
 def set_aux_stream(stream: Optional["torch.cuda.Stream"], device=None):
@@ -118,7 +133,8 @@ def _aux_stream():
     if st is None:
         return None
     h = st.cuda_stream
-    return None if h == torch.cuda.current_stream().cuda_stream else h
+    cur = torch.cuda.current_stream().cuda_stream
+    return None if (h == cur or cur in _NO_AUX) else h
 
 
 def _chk(code: int, name: str):
@@ -227,6 +243,37 @@ def dense_adapter_down_fwd(x, wm, bias_m, N1, z, *, y_f32=None, y_bf16=None, p_d
     _chk(load().fbl_dense_adapter_down_fwd(_p(x), ldx, _p(wm), ldw, M, N1, A, K, _p(bias_m), _p(y_f32), _p(y_bf16), ldy or 0,
                                            float(p_drop), int(seed), _p(z), ldz, _stream(), _aux_stream()),
          "fbl_dense_adapter_down_fwd")
+
+
+def adapter_up_resid_fwd(z, wu, bias_u, x, out_t, *, A=None, p_drop=0.0, seed=0, r_plain=None, r_norm=None):
+    """out_t[M,H] = dropout(x + z[:, :A] @ wu[:, :A]^T + bias_u) + residual (fp32): the adapter's up-projection with the
+    residual / dropout of the enclosing block in its epilogue.  residual: r_plain (fp32 [M,H]) or r_norm = (t, stats, gamma,
+    beta, rowmask|None), the LayerNorm-normalised form of fbl_ln_fwd.  Dropout keys as fbl_ln_fwd (seed, m*H + n)."""
+    _req(z, torch.bfloat16, "z"); _req(wu, torch.bfloat16, "wu"); _req(x, torch.bfloat16, "x"); _req(out_t, torch.float32, "out_t")
+    ldz, ldw, ldx, ldt = _rows2d(z, "z"), _rows2d(wu, "wu"), _rows2d(x, "x"), _rows2d(out_t, "out_t")
+    M, H = x.shape
+    A = wu.shape[1] if A is None else A
+    assert wu.shape[0] == H and z.shape[0] >= M and z.shape[1] >= A and out_t.shape[0] >= M and out_t.shape[1] >= H
+    if bias_u is not None:
+        _req(bias_u, torch.float32, "bias_u")
+    if (r_plain is None) == (r_norm is None):
+        raise ValueError("exactly one of r_plain / r_norm")
+    rs = rg = rb = rm = None
+    if r_norm is not None:
+        rt, rs, rg, rb, rm = r_norm
+        for t in (rt, rs, rg, rb):
+            _req(t, torch.float32, "r_norm")
+        assert rs.is_contiguous() and rs.numel() >= 2 * M
+        if rm is not None:
+            _req(rm, torch.int32, "rowmask")
+    else:
+        rt = r_plain
+        _req(rt, torch.float32, "r_plain")
+    ld_r = _rows2d(rt, "residual")
+    assert rt.shape[0] >= M and rt.shape[1] >= H
+    _chk(load().fbl_adapter_up_resid_fwd(_p(z), ldz, _p(wu), ldw, M, H, int(A), _p(bias_u), _p(x), ldx, float(p_drop),
+                                         int(seed), _p(rt), ld_r, _p(rs), _p(rg), _p(rb), _p(rm), _p(out_t), ldt,
+                                         _stream()), "fbl_adapter_up_resid_fwd")
 
 
 def gemm_tn_acc(A, B, out_f32, ws, *, M=None, N=None, K=None, splitk=8):

@@ -38,9 +38,11 @@ enum {
   FBL_AUX_ADD_BF16 = 2,       /* out = act(..) + aux_bf16[m,n]                                                    */
   FBL_AUX_MUL_DGELU_BF16 = 3, /* out = (..) * gelu'(aux_bf16[m,n])   (backward of deberta.py:310-313)            */
   FBL_AUX_MUL_POS_BF16 = 4,   /* out = (..) * (aux_bf16[m,n] > 0)    (backward of adapter.py:39 ReLU[+dropout])  */
-  FBL_AUX_MUL_BF16 = 5        /* out = (..) * aux_bf16[m,n]          (aux = gelu' saved by FBL_ACT_GELU_GRAD)    */
+  FBL_AUX_MUL_BF16 = 5,       /* out = (..) * aux_bf16[m,n]          (aux = gelu' saved by FBL_ACT_GELU_GRAD)    */
+  FBL_AUX_ADAPTER_TAIL = 6    /* internal to fbl_adapter_up_resid_fwd; fbl_gemm_bf16_nt rejects it                */
 };
 
+/* Bumped whenever an exported argument list changes (3: this header); the ctypes binding refuses any other value. */
 int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
@@ -90,6 +92,20 @@ int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, i
 int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1, int A,
                                int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
                                uint64_t seed, void* z_bf16, int64_t ldz, void* stream, void* aux_stream);
+
+/* Everything between an adapter's bottleneck and the LayerNorm statistics behind it, as the epilogue of the up-projection:
+ *   t[M, H] = dropout_p( x[M,H] + z[M,A] . Wu[H,A]^T + bu ) + resid[M,H]                      (fp32 out, row stride ldt)
+ * x: the adapter's input (the dense layer's output, bf16); resid either plain fp32 (r_stats == NULL: r_t[m,n], row stride
+ * ld_r) or in LayerNorm-normalised form ((r_t[m,n] - r_stats[2m]) * r_stats[2m+1] * r_gamma[n] + r_beta[n]) * r_rowmask[m]
+ * (r_rowmask int32 or NULL) -- the representation fbl_ln_fwd leaves behind (out_t, out_stats).  Dropout keys as in
+ * fbl_ln_fwd: element (m, n) by (seed, m*H + n), so fbl_ln_bwd regenerates the same mask.  t is the pre-norm tensor of the
+ * following LayerNorm: fbl_ln_fwd(y = t, no dropout, no residual, out_t = NULL) completes the block.  The adapter output
+ * never reaches HBM on its own.  A % 64 == 0 (K of the GEMM), H % 4 == 0, ldz/ldw/ldx % 8 == 0, ldt/ld_r % 4 == 0.
+ * ref: model/adapter.py:42-45 (up + residual), model/deberta.py:258-259, 332-333 (dropout; LayerNorm(. + input_tensor)). */
+int fbl_adapter_up_resid_fwd(const void* z_bf16, int64_t ldz, const void* wu_bf16, int64_t ldw, int M, int H, int A,
+                             const float* bias_u, const void* x_bf16, int64_t ldx, float p_drop, uint64_t seed,
+                             const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
+                             const float* r_beta, const int32_t* r_rowmask, float* out_t, int64_t ldt, void* stream);
 
 /* Weight and bias gradients of a GROUP of bottleneck adapters of one shape, accumulated (+=) by ONE launch:
  *     dWu[o][H,A] += sum_s dy_s^T . z_s      dWd[o][A,H] += sum_s dz_s^T . x_s      dbd[o][A] += sum_s colsum(dz_s)

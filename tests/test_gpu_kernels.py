@@ -826,3 +826,50 @@ def test_dense_adapter_down_merged(L, M, N1, A, K):
         with pytest.raises(RuntimeError):
             L.dense_adapter_down_fwd(x[:, :K], Wm[: 100 + A], bm[: 100 + A].contiguous(), 100, z, y_f32=y32[:, :100].contiguous())
     close(z2.float()[keep], z.float()[keep] / (1 - p), 2e-2, 1e-2, "kept values")
+
+
+@pytest.mark.parametrize("M,H,A", [(203, 128, 64), (8512, 1536, 192), (1000, 768, 128), (4100, 1536, 192), (333, 256, 64)])
+def test_adapter_up_resid_tail(L, M, H, A):
+    """fbl_adapter_up_resid_fwd: t = dropout(x + z.Wu^T + bu) + residual, residual plain or LayerNorm-normalised with a row
+    mask; the dropout mask is the one fbl_ln_fwd / fbl_ln_bwd generate from the same seed; fbl_ln_fwd(y = t) then gives the
+    same statistics / bf16 operand as the unfused block (up GEMM -> fbl_ln_fwd with dropout and residual)."""
+    eps = 1e-7
+    z = bf(torch.relu(rnd(M, A, seed=1))).to(BF16)
+    Wu = bf(rnd(H, A, seed=2, scale=0.05)).to(BF16)
+    bu = rnd(H, seed=3, scale=0.1)
+    x = bf(rnd(M, H, seed=4)).to(BF16)
+    r = rnd(M, H, seed=5)
+    y_ref = x.float() + z.float() @ Wu.float().t() + bu
+    # (a) plain residual, no dropout
+    t = torch.full((M, H), 9.0, device=DEV)
+    L.adapter_up_resid_fwd(z, Wu, bu, x, t, r_plain=r)
+    close(t, y_ref + r, 1e-4, 2e-3, "plain residual")
+    # (b) normalised residual with row mask: the representation fbl_ln_fwd leaves behind
+    g, b = 1 + 0.1 * rnd(H, seed=6), 0.1 * rnd(H, seed=7)
+    rowmask = (torch.arange(M, device=DEV) % 7 != 0).to(torch.int32)
+    rt = torch.empty(M, H, device=DEV); rst = torch.empty(M, 2, device=DEV); rf = torch.empty(M, H, device=DEV)
+    L.ln_fwd(y=r, gamma=g, beta=b, eps=eps, rowmask=rowmask, out_t=rt, out_stats=rst, out_f32=rf, N=M, H=H)
+    t2 = torch.empty(M, H, device=DEV)
+    L.adapter_up_resid_fwd(z, Wu, bu, x, t2, r_norm=(rt, rst, g, b, rowmask))
+    close(t2, y_ref + rf, 1e-4, 2e-3, "normalised residual")
+    # (c) dropout: against the unfused block on the same fp32 adapter output
+    p, seed = 0.1, 424242
+    t3 = torch.empty(M, H, device=DEV)
+    L.adapter_up_resid_fwd(z, Wu, bu, x, t3, p_drop=p, seed=seed, r_norm=(rt, rst, g, b, rowmask))
+    y32 = torch.empty(M, H, device=DEV)
+    L.gemm(z, Wu, bias=bu, aux=x.float().contiguous(), aux_kind=L.AUX_ADD_F32, out_f32=y32)
+    g2, b2 = 1 + 0.1 * rnd(H, seed=8), 0.1 * rnd(H, seed=9)
+    t_ref = torch.empty(M, H, device=DEV); st_ref = torch.empty(M, 2, device=DEV); ob_ref = torch.empty(M, H, dtype=BF16, device=DEV)
+    L.ln_fwd(y=y32, p_drop=p, seed=seed, r_norm=(rt, rst, g, b, rowmask), gamma=g2, beta=b2, eps=eps, out_t=t_ref,
+             out_stats=st_ref, out_bf16=ob_ref, N=M, H=H)
+    close(t3, t_ref, 1e-4, 2e-3, "dropout + residual vs unfused block")
+    dropped = (t3 - rf).abs() < 1e-6  # dropped elements: t == residual
+    assert abs(dropped.float().mean().item() - p) < 0.02
+    st = torch.empty(M, 2, device=DEV); ob = torch.empty(M, H, dtype=BF16, device=DEV)
+    L.ln_fwd(y=t3, gamma=g2, beta=b2, eps=eps, out_stats=st, out_bf16=ob, N=M, H=H)
+    close(st[:, 0], st_ref[:, 0], 1e-4, 1e-4, "mean")
+    close(st[:, 1], st_ref[:, 1], 1e-3, 1e-4, "rstd")
+    close(ob, ob_ref, 2e-2, 2e-2, "bf16 operand")
+    # argument contract: the generic GEMM entry refuses the internal epilogue kind
+    with pytest.raises(RuntimeError):
+        L.gemm(z, Wu, bias=bu, aux=x, aux_kind=6, out_f32=t)
