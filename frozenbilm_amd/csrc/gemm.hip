@@ -339,6 +339,18 @@ static inline bool big_tile_shape(int M, int N, int batch) {
   return batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
 }
 
+static int device_cu_count() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+
+
 // out[b][m][n] += sum_ks ws[b][ks][m][n]   (deterministic split-K fold)
 __global__ void splitk_reduce_kernel(const float* ws, int splitk, int M, int N, int Nw, float* out, long ldc, long sC) {
   const int b = blockIdx.y;

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     return;
   }
   const int ec = (lane & 15) * 4;
-  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
+  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3, R224>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
                                     0, 0, short_rows ? 48 : 64);
 }
 

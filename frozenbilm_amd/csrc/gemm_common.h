@@ -237,7 +237,8 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmArgs& g, char* smem
 //   its second wave row 48 of them); rows beyond it are not stored.
 // DBG (measurement builds only): bit 0 = everything but the global stores (values kept alive), bit 1 = the stores of all
 // tile rows alias the first 256 rows of C (the output stays L2-resident: store issue without HBM write traffic)
-template <int ACT, int AUX, bool SPLITK, int MI, int DBG = 0>
+// SHORT48: slab_rows may be 48 (second wave row of the 224-row 8-phase tile): gets its own branch-free row loop.
+template <int ACT, int AUX, bool SPLITK, int MI, int DBG = 0, bool SHORT48 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
                                               int m_first, int m_slab_stride, int n4, int batch, int ks,
                                               int slab_rows = 64) {
@@ -263,9 +264,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
     for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
   }
   const bool full = (n4 + 3 < g.N);
-#pragma unroll
-  for (int half = 0; half < (MI + 3) / 4; ++half) {  // the wave tile leaves in slabs of (up to) 64 rows
-    const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
+  // every lane of the wave stores whole 4-column vectors (wave-uniform): together with "all rows of the slab exist" this
+  // selects the branch-free copy of the row loop below
+  const bool wave_full = vec_ok && __builtin_amdgcn_ballot_w64(full) == ~0ull;
+  // (the two slabs are two calls of one generic lambda, not a loop: whatever the unroller thinks of the body's size, the
+  //  accumulator indices stay compile-time constants -- a rolled loop would put the accumulator array into scratch memory)
+  auto slab = [&](auto halfc) {
+    constexpr int half = decltype(halfc)::value;
+    constexpr int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
     const int mslab = m_first + half * m_slab_stride;
     // The aux operand of the slab is requested BEFORE the accumulators make their LDS round trip: issued inside the
     // row loop, every iteration exposed a full global-load latency (32 dependent loads per wave on a 256x256 tile).
@@ -316,14 +322,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
     const long er_x = xbase + (long)(mslab + er) * g.ld_aux + n4;
     // (two copies of the row loop, selected by the wave-uniform aux_fast: the slow path loads aux inside the loop, and a
     //  join of "maybe a load is pending" with the fast path would put a vmcnt(0) into every iteration of both)
-    auto row_loop = [&](auto fastc) {
+    // Three more copies per aux mode, selected by wave-uniform conditions: INNER = 64 / 48: an interior slab -- all its rows
+    // exist, every lane stores full vectors -- runs WITHOUT per-row predicates, so the compiler interleaves the LDS reads,
+    // transcendental chains and stores of the 16 (12) row iterations instead of branching around each of them (the predicated
+    // copy spends most of its time in exposed latencies: 4-13 us per 256x256 tile); INNER = 0: edge slabs, predicated.
+    // The interior copies are further specialised by the set of outputs (OUTS: 1 fp32, 2 bf16, 6 bf16 + pre-activation, 0 =
+    // any, tested per row): a run-time "is this output wanted" test around a store is a branch per row too.
+    auto row_loop = [&](auto fastc, auto innerc, auto outsc) {
     constexpr bool AUXFAST = decltype(fastc)::value;
+    constexpr int INNER = decltype(innerc)::value;
+    constexpr int OUTS = decltype(outsc)::value;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       if (it >= cnt * 4) break;
+      if (INNER && it * 4 >= INNER) break;
       const int row = it * 4 + er;
       const int m = mslab + row;
-      if (m >= g.M || row >= slab_rows) continue;
+      if (!INNER && (m >= g.M || row >= slab_rows)) continue;
       const f32x4 a4 = *(const f32x4*)(stage + row * LDW + ec);
       const float rs = rsv[it];
       float v[4], pre[4];
@@ -379,7 +394,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       const long co = er_c + (long)(it * 4) * g.ldc;
       if (DBG & 1) {
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]), "v"(co));
-      } else if (full && vec_ok) {
+      } else if (INNER && OUTS) {
+        if (OUTS & 1) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
+        if (OUTS & 2) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if (OUTS & 4) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};
+      } else if (INNER || (full && vec_ok)) {
         if (g.out_f32) *(f32x4*)(g.out_f32 + co) = (f32x4){v[0], v[1], v[2], v[3]};
         if (g.out_bf16) *(bf16x4*)(g.out_bf16 + co) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         if (g.out_pre) *(bf16x4*)(g.out_pre + co) = (bf16x4){f2bf(pre[0]), f2bf(pre[1]), f2bf(pre[2]), f2bf(pre[3])};
@@ -393,15 +412,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       }
     }
     };
-    if (AUX != FBL_AUX_NONE && aux_fast) row_loop(std::true_type{});
-    else row_loop(std::false_type{});
+    const int rows_here = min(slab_rows, cnt * 16);
+    const bool inner = !SPLITK && wave_full && mslab + rows_here <= g.M;
+    using I0 = std::integral_constant<int, 0>;
+    using I48 = std::integral_constant<int, 48>;
+    using I64 = std::integral_constant<int, 64>;
+    const int outs = (g.out_f32 ? 1 : 0) | (g.out_bf16 ? 2 : 0) | (g.out_pre ? 4 : 0);
+    auto by_outs = [&](auto fastc, auto innerc) {
+      using O = std::integral_constant<int, 0>;
+      if (outs == 2) row_loop(fastc, innerc, std::integral_constant<int, 2>{});
+      else if (outs == 1) row_loop(fastc, innerc, std::integral_constant<int, 1>{});
+      else if (outs == 6 && ACT != FBL_ACT_NONE) row_loop(fastc, innerc, std::integral_constant<int, 6>{});
+      else row_loop(fastc, innerc, O{});
+    };
+    if (AUX != FBL_AUX_NONE && aux_fast) {
+      if (inner && rows_here == cnt * 16) by_outs(std::true_type{}, I64{});
+      else if (SHORT48 && inner && rows_here == 48) by_outs(std::true_type{}, I48{});
+      else row_loop(std::true_type{}, I0{}, I0{});
+    } else if (AUX == FBL_AUX_NONE) {
+      if (inner && rows_here == cnt * 16) by_outs(std::false_type{}, I64{});
+      else if (SHORT48 && inner && rows_here == 48) by_outs(std::false_type{}, I48{});
+      else row_loop(std::false_type{}, I0{}, I0{});
+    } else {
+      row_loop(std::false_type{}, I0{}, I0{});
     }
-  }
+    }
+  };
+  slab(std::integral_constant<int, 0>{});
+  if constexpr ((MI + 3) / 4 > 1) slab(std::integral_constant<int, 1>{});
 }
 
 // 8-phase 256x256 kernel (gemm8.hip).  Returns 0 when launched, FBL_ERR_ARG for an epilogue combination it does not
 // instantiate (the caller then uses the 2-stage kernel).
 int launch_gemm8(const GemmArgs& g, int act, int aux_kind, bool rows224, dim3 grid, hipStream_t stream);
 bool gemm8_eligible(const GemmArgs& g);
+
 
 }  // namespace fblgemm

@@ -254,7 +254,13 @@ class Engine:
         return self._relidx[S]
 
     def _refresh_if_stale(self, need_grad: bool):
-        ver = (self.params_version, tuple(self.named[n]._version for n in self.order)) if not need_grad else None
+        """bf16 operands / composed adapter rows follow the trainable parameters: rebuilt before EVERY forward by default
+        (0.2 ms of GPU time).  Only inside `model.weights_frozen()` -- the evaluate loops, the inference-graph path -- is the
+        rebuild skipped while nothing the engine can see has written to them: FusedAdam.step (params_version) and in-place
+        updates through the parameter objects (autograd version counters).  Writes through `.data`, into `engine.flat` or by
+        a broadcast into the flat buffer bump neither counter, which is why skipping is opt-in."""
+        frozen = getattr(self.m, "_weights_frozen", 0) > 0
+        ver = (self.params_version, tuple(self.named[n]._version for n in self.order)) if (frozen and not need_grad) else None
         if ver is None or ver != self._ops_version:
             self.refresh_trainable_operands()
             self._ops_version = ver
@@ -445,11 +451,7 @@ class Engine:
         run.mask = mask.view(-1)
         run.labels = full_labels
         run.rows = rows_labelled if full_labels is not None else None
-        # bf16 operands / composed adapter rows follow the trainable parameters.  An inference forward skips the rebuild
-        # when nothing wrote to them since the last one: writers are FusedAdam.step (params_version) and in-place updates
-        # through the parameter objects (their autograd version counters: torch optimizers, p.copy_()).  Code that
-        # writes through `.data` behind autograd's back calls engine.invalidate_operands().
-        self._refresh_if_stale(need_grad)
+        self._refresh_if_stale(need_grad)  # bf16 operands / composed adapter rows of the trainable parameters
         use_ans = bool(m.n_ans) and not mlm
         if logit_rows is not None:
             if need_grad or full_labels is not None:

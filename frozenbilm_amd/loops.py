@@ -32,15 +32,54 @@ def video_inputs(batch_dict, device):
     return video, get_mask(batch_dict["video_len"], video.size(1)).to(device)
 
 
-def logged_loss(name: str, loss, stop_on_nonfinite: bool = True):
-    """All-reduced loss dict for logging + its scalar; in training a non-finite loss stops the run (main.py:70-78)."""
-    reduced = dist.reduce_dict({name: loss})
-    value = sum(reduced.values()).item()
-    if stop_on_nonfinite and not math.isfinite(value):
-        print("Loss is {}, stopping training".format(value))
-        print(reduced)
-        sys.exit(1)
-    return reduced, value
+class LossLog:
+    """The per-step loss bookkeeping of the training / evaluation loops (main.py:70-78, videoqa.py:84-95, mc.py:94-105):
+    all-reduce the loss dict for logging, stop the run on a non-finite training loss, feed the meters.
+
+    The reference reads the loss on the host (`.item()`) before it calls backward, i.e. the host waits for the forward in
+    flight and the GPU then waits for the host to enqueue the backward.  Default here: exactly that.  With
+    ``args.delayed_loss_check`` (opt-in) the reduced loss of step i goes to pinned host memory by an asynchronous copy and
+    is checked / logged when step i+1 calls -- the copy has long finished, nothing waits -- and `flush()` (called by
+    `EpochRunner.finish`) handles the last step.  A non-finite loss is then noticed one step late: the run still stops
+    after one more optimizer step than the reference would have applied; the returned averages are identical."""
+
+    def __init__(self, run: "EpochRunner", name: str, stop_on_nonfinite: bool = True, delayed: bool = False):
+        self.run, self.name, self.stop, self.delayed = run, name, stop_on_nonfinite, delayed
+        self.pending = None
+        run.loss_log = self
+
+    def _emit(self, reduced_host):
+        value = float(sum(reduced_host.values()))
+        if self.stop and not math.isfinite(value):
+            print("Loss is {}, stopping training".format(value))
+            print(reduced_host)
+            sys.exit(1)
+        self.run.log(loss=value, **reduced_host)
+
+    def __call__(self, loss):
+        reduced = dist.reduce_dict({self.name: loss})
+        if not (self.delayed and all(torch.is_tensor(v) and v.is_cuda for v in reduced.values())):
+            self._emit({k: (v.item() if torch.is_tensor(v) else float(v)) for k, v in reduced.items()})
+            return
+        self.flush()
+        keys = list(reduced)
+        host = torch.empty(len(keys), dtype=torch.float32).pin_memory()
+        host.copy_(torch.stack([reduced[k].detach().float().reshape(()) for k in keys]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (keys, host, ev)
+
+    def flush(self):
+        if self.pending is not None:
+            keys, host, ev = self.pending
+            self.pending = None
+            ev.synchronize()
+            self._emit({k: float(host[i]) for i, k in enumerate(keys)})
+
+
+def frozen_weights(model):
+    """`model.weights_frozen()` where the model has it (the MI355X model), a null context otherwise (test doubles)"""
+    return model.weights_frozen() if hasattr(model, "weights_frozen") else contextlib.nullcontext()
 
 
 def optimizer_step(loss, optimizer, model, max_norm, reducer=None):
@@ -78,6 +117,8 @@ class EpochRunner:
         self.logger.update(**scalars)
 
     def finish(self, synchronize=True):
+        if getattr(self, "loss_log", None) is not None:
+            self.loss_log.flush()
         if synchronize:
             self.logger.synchronize_between_processes()
             print("Averaged stats:", self.logger)

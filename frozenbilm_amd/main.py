@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
 from .util.misc import mask_tokens
 
 
@@ -32,13 +32,13 @@ def _prepare(batch_dict, tokenizer, device, args, step_seed=0):
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, args, max_norm):
     model.train()
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
+    log = LossLog(run, "mlm_loss", delayed=getattr(args, "delayed_loss_check", False))
     for i_batch, batch_dict in run:
         feed = _prepare(batch_dict, tokenizer, device, args, step_seed=run.global_step(i_batch) + 1)
         loss = model(**feed)["loss"]
-        reduced, value = logged_loss("mlm_loss", loss)
+        log(loss)  # (main.py:70-78; one step late with args.delayed_loss_check)
         optimizer_step(loss, optimizer, model, max_norm)
         run.schedule(optimizer, i_batch)
-        run.log(loss=value, **reduced)
     return run.finish()
 
 
@@ -46,8 +46,8 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
 def evaluate(model, tokenizer, data_loader, device, args):
     model.eval()
     run = EpochRunner(data_loader, args, "Val:")
-    for _, batch_dict in run:
-        loss = model(**_prepare(batch_dict, tokenizer, device, args))["loss"]
-        reduced, value = logged_loss("mlm_loss", loss, stop_on_nonfinite=False)
-        run.log(loss=value, **reduced)
+    log = LossLog(run, "mlm_loss", stop_on_nonfinite=False, delayed=getattr(args, "delayed_loss_check", False))
+    with frozen_weights(model):
+        for _, batch_dict in run:
+            log(model(**_prepare(batch_dict, tokenizer, device, args))["loss"])
     return run.finish(synchronize=False)

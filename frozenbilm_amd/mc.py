@@ -11,7 +11,7 @@ from functools import reduce
 import torch
 import torch.nn.functional as F
 
-from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
 from .util import dist
 from .videoqa import answer_logits
 
@@ -64,13 +64,13 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
     # several forwards feed one step: under data parallelism the gradient exchange waits for the last backward pass
     reducer = getattr(model.engine(), "reducer", None) if hasattr(model, "engine") else None
+    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False))
     for i_batch, batch_dict in run:
         scores = candidate_scores(model, tokenizer, batch_dict, device, args)
         loss = mc_loss(scores, batch_dict["answer_id"].to(device), data_loader.dataset.mc)
-        reduced, value = logged_loss("cls_loss", loss)
+        log(loss)
         optimizer_step(loss, optimizer, model, max_norm, reducer=reducer)
         run.schedule(optimizer, i_batch)
-        run.log(loss=value, **reduced)
         run.log(lr=optimizer.param_groups[0]["lr"])
     return run.finish()
 
@@ -82,24 +82,25 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, split="t
         model.inference_graphs = True  # replay the per-batch forward as one hipGraph (fixed batch shapes pay off most)
     run = EpochRunner(data_loader, args, f"{split}:")
     res = {}
-    for _, batch_dict in run:
-        scores = candidate_scores(model, tokenizer, batch_dict, device, args)
-        preds = scores.round().long().squeeze(1) if scores.shape[1] == 1 else scores.max(1).indices
-        qids, types = batch_dict["qid"], batch_dict["type"]
-        if batch_dict["answer_id"][0].item() != -1:
-            answer_id = batch_dict["answer_id"].to(device)
-            agreeings = preds == answer_id
-            # one device-to-host copy per tensor instead of three .item() synchronisations per question
-            preds_h, gts_h, agr_h = preds.tolist(), answer_id.tolist(), agreeings.tolist()
-            for i, (qid, type_) in enumerate(zip(qids, types)):
-                res[qid] = {"pred": preds_h[i], "gt": gts_h[i]}
-                if type_map is not None and len(type_map) > 1:
-                    res[qid]["type"] = int(type_)
-                res[qid]["acc"] = agr_h[i]
-            run.log(acc=dist.reduce_dict({"acc": agreeings.sum() / len(qids)})["acc"].item())
-        else:  # hidden test set: predictions only (mc.py:205-207)
-            for qid, pred in zip(qids, preds.tolist()):
-                res[str(qid)] = int(pred)
+    with frozen_weights(model):  # nothing writes to the parameters during an evaluation: packed operands are reused
+        for _, batch_dict in run:
+            scores = candidate_scores(model, tokenizer, batch_dict, device, args)
+            preds = scores.round().long().squeeze(1) if scores.shape[1] == 1 else scores.max(1).indices
+            qids, types = batch_dict["qid"], batch_dict["type"]
+            if batch_dict["answer_id"][0].item() != -1:
+                answer_id = batch_dict["answer_id"].to(device)
+                agreeings = preds == answer_id
+                # one device-to-host copy per tensor instead of three .item() synchronisations per question
+                preds_h, gts_h, agr_h = preds.tolist(), answer_id.tolist(), agreeings.tolist()
+                for i, (qid, type_) in enumerate(zip(qids, types)):
+                    res[qid] = {"pred": preds_h[i], "gt": gts_h[i]}
+                    if type_map is not None and len(type_map) > 1:
+                        res[qid]["type"] = int(type_)
+                    res[qid]["acc"] = agr_h[i]
+                run.log(acc=dist.reduce_dict({"acc": agreeings.sum() / len(qids)})["acc"].item())
+            else:  # hidden test set: predictions only (mc.py:205-207)
+                for qid, pred in zip(qids, preds.tolist()):
+                    res[str(qid)] = int(pred)
     all_res = dist.all_gather(res)
     results = reduce(lambda a, b: a.update(b) or a, all_res, {})
     assert len(results) == len(data_loader.dataset)

@@ -224,6 +224,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
         self._engine = None
         self.inference_graphs = False  # opt-in: replay the `logit_rows` inference forward as one hipGraph (_graph_forward)
+        self._weights_frozen = 0  # nesting depth of weights_frozen(): inference forwards may reuse the packed operands
         self._reducer = None  # parallel.GradReducer attached to this model (survives engine rebuilds)
         self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
         self._seed_salt = None  # torch seed (args.seed + rank in the reference's main()) and rank, fixed at first use
@@ -287,6 +288,25 @@ class DebertaV2ForMaskedLM(nn.Module):
         self.get_param("answer_bias").requires_grad_(False)
         self.invalidate()
 
+    def weights_frozen(self):
+        """Context manager: inside it the caller promises not to modify the trainable parameters behind the engine's back
+        (through `.data`, `vector_to_parameters`, raw writes into `engine().flat`), so inference forwards skip the rebuild
+        of the bf16 operands / composed adapter rows unless FusedAdam.step or an in-place update through a parameter object
+        happened in between.  Outside it every forward rebuilds them.  The evaluate loops run inside it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self._weights_frozen += 1
+            try:
+                yield self
+            finally:
+                self._weights_frozen -= 1
+                if self._weights_frozen == 0 and self._engine is not None:
+                    self._engine._ops_version = None
+
+        return scope()
+
     def invalidate(self):
         """Drop the packed bf16 operands / flat buffers (after load_state_dict, .to(), set_answer_embeddings)."""
         self._engine = None
@@ -345,7 +365,8 @@ class DebertaV2ForMaskedLM(nn.Module):
         Returns None when the configuration cannot be captured (the caller then takes the eager path)."""
         import torch.nn.functional as F_
 
-        # operands of the trainable weights / composed adapter rows are rebuilt (in place) outside the graph when needed
+        # operands of the trainable weights / composed adapter rows are rebuilt (in place) outside the graph: on every call,
+        # or -- inside weights_frozen(), where the evaluate loops run -- only when something wrote to the parameters
         eng.prepare_inference()
         B, Lt = input_ids.shape
         T = video.shape[1] if (video is not None and eng.F) else 0

@@ -11,7 +11,7 @@ from functools import reduce
 import torch
 import torch.nn.functional as F
 
-from .loops import EpochRunner, logged_loss, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
 from .util import dist
 
 
@@ -69,6 +69,7 @@ def topk_agreement(logits, answer_id, dataset_name, thresholds):
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dataset_name, args, max_norm: float = 0):
     model.train()
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
+    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False))
     for i_batch, batch_dict in run:
         video, video_mask = video_inputs(batch_dict, device)
         encoded = tokenize(tokenizer, batch_dict["text"], args)
@@ -76,10 +77,9 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dat
                        attention_mask=encoded["attention_mask"].to(device))
         logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
         loss = vqa_loss(logits, batch_dict["answer_id"].to(device), dataset_name)
-        reduced, value = logged_loss("cls_loss", loss)
+        log(loss)
         optimizer_step(loss, optimizer, model, max_norm)
         run.schedule(optimizer, i_batch)
-        run.log(loss=value, **reduced)
         run.log(lr=optimizer.param_groups[0]["lr"])
     return run.finish()
 
@@ -92,28 +92,29 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, threshol
         model.inference_graphs = True  # replay the per-batch forward as one hipGraph (fixed batch shapes pay off most)
     run = EpochRunner(data_loader, args, f"{split}:")
     res = {}
-    for _, batch_dict in run:
-        video, video_mask = video_inputs(batch_dict, device)
-        encoded = tokenize(tokenizer, batch_dict["text"], args)
-        input_ids = encoded["input_ids"].to(device)
-        attention_mask = encoded["attention_mask"].to(device)
-        if not args.suffix and not args.use_context:  # remove sep token if not using the suffix (videoqa.py:152-156)
-            attention_mask[input_ids == tokenizer.sep_token_id] = 0
-            input_ids[input_ids == tokenizer.sep_token_id] = tokenizer.pad_token_id
-        logits = answer_logits(model, tokenizer, encoded["input_ids"], args, video=video, video_mask=video_mask,
-                               input_ids=input_ids, attention_mask=attention_mask)
-        answer_id, qids = batch_dict["answer_id"].to(device), batch_dict["qid"]
-        types = batch_dict["type"]
-        subs = batch_dict["sub"] if "sub" in batch_dict else [0] * len(types)
-        topk_aids, gts, agreeings = topk_agreement(logits, answer_id, dataset_name, thresholds)
-        # one device-to-host copy per tensor instead of (2 + thresholds) synchronisations per question
-        preds_h, gts_h = topk_aids.tolist(), gts.tolist()
-        acc_h = {x: agreeings[x].reshape(len(qids), -1).sum(1).tolist() for x in thresholds}
-        for i, (qid, type_, sub) in enumerate(zip(qids, types, subs)):
-            res[qid] = {"pred": preds_h[i], "gt": gts_h[i], "type": int(type_), "sub": sub}
-            for x in thresholds:
-                res[qid][f"acc{x}"] = acc_h[x][i]
-        run.log(acc=dist.reduce_dict({"acc": agreeings[1].sum() / len(qids)})["acc"].item())
+    with frozen_weights(model):  # nothing writes to the parameters during an evaluation: packed operands are reused
+        for _, batch_dict in run:
+            video, video_mask = video_inputs(batch_dict, device)
+            encoded = tokenize(tokenizer, batch_dict["text"], args)
+            input_ids = encoded["input_ids"].to(device)
+            attention_mask = encoded["attention_mask"].to(device)
+            if not args.suffix and not args.use_context:  # remove sep token if not using the suffix (videoqa.py:152-156)
+                attention_mask[input_ids == tokenizer.sep_token_id] = 0
+                input_ids[input_ids == tokenizer.sep_token_id] = tokenizer.pad_token_id
+            logits = answer_logits(model, tokenizer, encoded["input_ids"], args, video=video, video_mask=video_mask,
+                                   input_ids=input_ids, attention_mask=attention_mask)
+            answer_id, qids = batch_dict["answer_id"].to(device), batch_dict["qid"]
+            types = batch_dict["type"]
+            subs = batch_dict["sub"] if "sub" in batch_dict else [0] * len(types)
+            topk_aids, gts, agreeings = topk_agreement(logits, answer_id, dataset_name, thresholds)
+            # one device-to-host copy per tensor instead of (2 + thresholds) synchronisations per question
+            preds_h, gts_h = topk_aids.tolist(), gts.tolist()
+            acc_h = {x: agreeings[x].reshape(len(qids), -1).sum(1).tolist() for x in thresholds}
+            for i, (qid, type_, sub) in enumerate(zip(qids, types, subs)):
+                res[qid] = {"pred": preds_h[i], "gt": gts_h[i], "type": int(type_), "sub": sub}
+                for x in thresholds:
+                    res[qid][f"acc{x}"] = acc_h[x][i]
+            run.log(acc=dist.reduce_dict({"acc": agreeings[1].sum() / len(qids)})["acc"].item())
 
     all_res = dist.all_gather(res)
     results = reduce(lambda a, b: a.update(b) or a, all_res, {})

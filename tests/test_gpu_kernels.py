@@ -40,7 +40,10 @@ def close(got, ref, rtol, atol, name=""):
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 130, 128), (1000, 1536, 1536), (333, 192, 1536), (256, 4608, 192),
                                    (130, 6, 64), (4100, 2052, 128), (8512, 1536, 192), (4100, 3584, 128), (8512, 192, 1536),
-                                   (2100, 70, 64), (4100, 3500, 256), (4100, 3584, 1536), (8512, 6144, 384), (8512, 1536, 384), (4100, 2052, 256)])
+                                   (2100, 70, 64), (4100, 3500, 256), (4100, 3584, 1536), (8512, 6144, 384), (8512, 1536, 384), (4100, 2052, 256),
+                                   (4100, 4608, 256), (4100, 4500, 192), (2500, 8192, 128), (8512, 6144, 1536)])
+# the last four: more than one round of 256x256 tiles (skewed single launch / whole rounds + remainder rows), K = 4, 3, 2 and
+# 24 K-tiles (3 and 2: below the 8-phase kernel's shortest pipeline -> 2-stage 256x256 tiles), ragged last tile column / row;
 # (4100,35xx,K>=256): the 8-phase 256x256 kernel (gemm8.hip; K = 256 is its shortest pipeline, N = 3500 a ragged last column
 # tile); (8512,6144): 8-phase tiles for the whole rounds + 64x128 tiles for the remaining rows (helper stream); (8512,1536,384) and
 # (4100,2052,256): 224-row 8-phase tiles (second wave row with three 16-row MFMA tiles per half);
@@ -70,8 +73,10 @@ def test_gemm_asymmetric_identity(L):
     assert torch.equal(o, B.float().t())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4100, 2052, 64), (4100, 3584, 64), (4100, 192, 128), (4100, 3584, 256), (4100, 2052, 256)])
-# 128x128, 224x256, 256x256 and 64x128 tiles, 8-phase 256x256, 8-phase 224x256 (plain / residual-add) + its fallbacks
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4100, 2052, 64), (4100, 3584, 64), (4100, 192, 128), (4100, 3584, 256), (4100, 2052, 256),
+                                   (4100, 4608, 320)])
+# 128x128, 224x256, 256x256 and 64x128 tiles, 8-phase 256x256, 8-phase 224x256 (plain / residual-add) + its fallbacks,
+# a multi-round problem with an odd number of K-tiles (306 tiles of 256x256, K = 320: 2-stage 256x256 tiles)
 def test_gemm_epilogues(L, M, N, K):
     A, B = bf(rnd(M, K, seed=1)).to(BF16), bf(rnd(N, K, seed=2, scale=0.1)).to(BF16)
     bias = rnd(N, seed=3)
