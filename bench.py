@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--eval-forward", action="store_true", help="time the eval forward only (reported under its own metric)")
     ap.add_argument("--full-logits", action="store_true", help="read .logits in every timed step (reference-eager head)")
     ap.add_argument("--no-extras", action="store_true", help="skip the with_full_logits / eval_forward / host side measurements")
+    ap.add_argument("--no-inference-graphs", action="store_true",
+                    help="downstream workloads: leave the loops' opt-in args.inference_graphs off (eager launches)")
     ap.add_argument("--workload", default="mlm", choices=["mlm", "videoqa", "mc"],
                     help="mlm = BASELINE configs[1] (the headline); videoqa = configs[3] (zero-shot open-ended eval loop, "
                          "n_ans=1000); mc = configs[4] (4-way multiple choice, B=8, S=512)")
@@ -200,6 +202,7 @@ def main():
         sync()
 
     extras = {}
+    full_cfg = args.layers == 24 and B == 32 and Lt == 256
     if not args.no_extras and not args.eval_forward:
         def timed(fn, n):
             for _ in range(2):
@@ -247,10 +250,27 @@ def main():
         batch.clear(); batch.update(keep)
         extras["host"] = {"enqueue_ms_per_step": d * 1e3, "note": "wall time per step of the same launch sequence at B=1 "
                           "(GPU work per launch negligible): upper bound of the host cost of a step"}
+        if world == 1 and full_cfg:
+            # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
+            # and with the opt-in one-step-delayed loss check
+            n_l = max(4, min(args.steps, 8))
+            extras["train_one_epoch"] = {"note": "frozenbilm_amd.main.train_one_epoch over synthetic batches that start on the "
+                                                 "host (CPU mask_tokens, H2D copies, loss logging): the loop, not the step body",
+                                         "reference_order": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False),
+                                         "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only=args.eval_forward)
+
+    if not args.no_extras and not args.eval_forward and world == 1 and full_cfg:
+        # BASELINE configs[3] / configs[4] through the product's evaluate loops on the same model (last: the answer table is
+        # swapped in and the engine rebuilt), with the loops' opt-in inference graphs and with eager launches
+        for wl, key in (("videoqa", "videoqa_eval"), ("mc", "mc_eval")):
+            on = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=True)
+            off = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False)
+            on["eager_launches"] = {"value": off["value"], "ms_per_step": off["ms_per_step"]}
+            extras[key] = on
 
     if rank == 0:
         full = args.layers == 24 and B == 32 and Lt == 256
@@ -269,6 +289,9 @@ def main():
                        "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted"},
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
             "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
+            # data parallel: ranks RCCL's collectives ran over (0 = no reducer / not the nccl backend) and where in backward
+            # they are launched (parallel.GradReducer.overlap; FBL_DP_OVERLAP overrides the default for A/B runs)
+            "rccl_ranks": red.rccl_ranks if red is not None else 0, "dp_overlap": red.overlap if red is not None else None,
             "algorithmic_tflops_per_step": step_flops / 1e12,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build,
         }
@@ -279,28 +302,25 @@ def main():
         dist.destroy_process_group()
 
 
-def run_downstream(args):
+def measure_downstream(model, cfg, workload, steps, warmup, layers=24, graphs=True):
     """BASELINE configs[3] / configs[4] on one GPU: the product's videoqa.evaluate / mc.evaluate loops (reference
     signatures) over synthetic batches resident in HBM; a step = one batch through the loop body (forward, [MASK]-row
-    head, softmax, top-k / candidate arg-max).  Own metric names: these lines are not the headline."""
+    head, softmax, top-k / candidate arg-max).  `model` is put into eval mode and gets the workload's answer table
+    (set_answer_embeddings: n_ans = 1000 / 2).  graphs: `args.inference_graphs` of the loops (one hipGraph per batch shape)."""
     import types
 
     from frozenbilm_amd import mc as P_mc
     from frozenbilm_amd import videoqa as P_vqa
-    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    cfg = DebertaV2Config(num_hidden_layers=args.layers)
-    torch.manual_seed(0)
-    vqa = args.workload == "videoqa"
+    dev = model.device
+    vqa = workload == "videoqa"
     n_ans = 1000 if vqa else 2
-    model = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1, n_ans=n_ans)
-    model.to(dev).eval()
+    model.eval()
     g = torch.Generator().manual_seed(5)
     a2tok = torch.randint(5, cfg.vocab_size, (n_ans, 5), generator=g)
     a2tok = a2tok * (torch.arange(5)[None] < torch.randint(1, 6, (n_ans, 1), generator=g))
     model.set_answer_embeddings(a2tok.to(dev))
+    model.inference_graphs = False
     MASK, B, T, F = 128000, (32 if vqa else 8), 10, 1024
     Lt = 256 if vqa else 502
     C = 1 if vqa else 4
@@ -326,7 +346,7 @@ def run_downstream(args):
                  answer_id=torch.randint(0, n_ans if vqa else C, (B,), generator=g),
                  text=texts(11) if vqa else [texts(11 + c) for c in range(C)])
     largs = types.SimpleNamespace(max_feats=T, use_video=True, suffix="", use_context=True, max_tokens=Lt, print_freq=10 ** 9,
-                                  inference_graphs=os.environ.get("FBL_NO_INFERENCE_GRAPHS", "0") != "1")
+                                  inference_graphs=bool(graphs))
 
     class Loader(list):
         dataset = list(range(B))
@@ -342,28 +362,100 @@ def run_downstream(args):
                 return P_vqa.evaluate(model, tok, Loader([batch]), dev, "msrvtt", largs, thresholds=[1, 10])
             return P_mc.evaluate(model, tok, Loader([batch]), dev, "how2qa", largs)
 
-    for _ in range(args.warmup + 3):
+    for _ in range(warmup + 3):
         step()
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
-        res = step()
+    for _ in range(steps):
+        step()
     torch.cuda.synchronize()
     dt = time.time() - t0
     S = T + Lt
     fwd_f, _ = algorithmic_flops_per_sample(S=S, V=n_ans)
-    tf = fwd_f * B * C * args.steps / dt / 1e12
-    out = {"metric": ("zero-shot open-ended VideoQA eval samples/sec (videoqa.evaluate, n_ans=1000)" if vqa else
-                      "multiple-choice VideoQA eval questions/sec (mc.evaluate, 4 candidates, S=512)"),
-           "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-           "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[{3 if vqa else 4}]: DeBERTa-v2-XLarge({args.layers}L)+adapters, B={B}, T=10x1024, L={Lt} "
-                                  f"(S={S}), n_ans={n_ans}, {C} candidate(s) per question in ONE forward of {B * C} samples, eval loop "
-                                  "incl. host-side result bookkeeping, head on the [MASK] rows only",
-                      "inference_graphs": len(model.__dict__.get("_graph_cache", {}))},
-           "candidate_forwards_per_s": B * C * args.steps / dt, "algorithmic_tflops": tf, "frac_of_peak": tf / PEAK_BF16_TFLOPS}
-    print(json.dumps(out))
+    tf = fwd_f * B * C * steps / dt / 1e12
+    n_graphs = len(model.__dict__.get("_graph_cache", {}))
+    model.inference_graphs = False
+    model.__dict__.pop("_graph_cache", None)
+    return {"metric": ("zero-shot open-ended VideoQA eval samples/sec (videoqa.evaluate, n_ans=1000)" if vqa else
+                       "multiple-choice VideoQA eval questions/sec (mc.evaluate, 4 candidates, S=512)"),
+            "value": B * steps / dt, "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{3 if vqa else 4}]: DeBERTa-v2-XLarge({layers}L)+adapters, B={B}, T=10x1024, L={Lt} "
+                                   f"(S={S}), n_ans={n_ans}, {C} candidate(s) per question in ONE forward of {B * C} samples, eval loop "
+                                   "incl. host-side result bookkeeping, head on the [MASK] rows only",
+                       "args.inference_graphs": bool(graphs), "inference_graphs_captured": n_graphs},
+            "candidate_forwards_per_s": B * C * steps / dt, "algorithmic_tflops": tf, "frac_of_peak": tf / PEAK_BF16_TFLOPS}
+
+
+def run_downstream(args):
+    """`--workload videoqa | mc`: the downstream line on its own (own metric names: not the headline).  The loops' opt-in
+    `args.inference_graphs` is on unless --no-inference-graphs; the line says which."""
+    from frozenbilm_amd.model import DebertaV2Config, DebertaV2ForMaskedLM
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = DebertaV2Config(num_hidden_layers=args.layers)
+    torch.manual_seed(0)
+    model = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1,
+                                 n_ans=1000 if args.workload == "videoqa" else 2)
+    model.to(dev).eval()
+    print(json.dumps(measure_downstream(model, cfg, args.workload, args.steps, args.warmup, args.layers,
+                                        graphs=not args.no_inference_graphs)))
+
+
+def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed):
+    """The product's `main.train_one_epoch` (reference signature, main.py:24-96) over `steps` synthetic batches: host-side
+    tokenisation stand-in + `mask_tokens` on the CPU generator + host-to-device copies + forward + loss logging + backward +
+    clip + Adam -- the headline times the step body on resident inputs, this is the loop a user runs.  delayed =
+    `args.delayed_loss_check` (the loss of step i is read when step i+1 calls instead of before its own backward)."""
+    import contextlib
+    import io
+    import types
+
+    from frozenbilm_amd import main as P_main
+
+    class Tok:
+        mask_token, _pad_token, pad_token_id, mask_token_id, cls_token_id, sep_token_id = "[MASK]", "[PAD]", 0, 128000, 1, 2
+
+        def __len__(self):
+            return cfg.vocab_size
+
+        def convert_tokens_to_ids(self, t):
+            return {"[MASK]": self.mask_token_id, "[PAD]": 0}[t]
+
+        def get_special_tokens_mask(self, row, already_has_special_tokens=True):
+            return [1 if v in (0, 1, 2, 128000) else 0 for v in row]
+
+        def __call__(self, text, **kw):
+            ids = torch.stack(text)
+            return {"input_ids": ids, "attention_mask": (ids != 0).long()}
+
+    g = torch.Generator().manual_seed(21)
+    batches = []
+    for _ in range(steps + 2):
+        tlen = torch.randint(Lt // 8, Lt + 1, (B,), generator=g)
+        tlen[-1] = Lt
+        ids = torch.randint(5, 127000, (B, Lt), generator=g) * (torch.arange(Lt)[None] < tlen[:, None])
+        vlen = torch.randint(1, T + 1, (B,), generator=g)
+        vlen[0] = T
+        batches.append(dict(video=torch.randn(B, T, F, generator=g).half().float(), video_len=vlen, text=list(ids)))
+
+    class Loader(list):
+        dataset = list(range(B * (steps + 2)))
+
+    largs = types.SimpleNamespace(max_tokens=Lt, mlm_prob=0.15, print_freq=10 ** 9, epochs=1, lr=3e-5, schedule="",
+                                  fraction_warmup_steps=0.1, delayed_loss_check=delayed)
+    model.train()
+    with contextlib.redirect_stdout(io.StringIO()):
+        P_main.train_one_epoch(model, Tok(), Loader(batches[:2]), opt, model.device, 0, largs, 0.1)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        P_main.train_one_epoch(model, Tok(), Loader(batches[2:]), opt, model.device, 0, largs, 0.1)
+        torch.cuda.synchronize()
+    dt = time.time() - t0
+    return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "args.delayed_loss_check": bool(delayed)}
 
 
 def spawn_ranks(n: int) -> int:

@@ -857,10 +857,16 @@ class Engine:
                 L.adapter_bwd_dw([([seg], self.G[nm + ".up.weight"], self.G[nm + ".down.weight"], self.G[nm + ".down.bias"])
                                   for nm, seg in recs], A=A)
             pend[:] = rest
-        if red is not None:  # a stage is final once every product parked before its end has been launched
-            lo = min((rec[3] for rec in pend), default=run.dw_count)
-            while run.dw_ready_keys and run.dw_ready_keys[0][1] <= lo:
-                red.ready(run.dw_ready_keys.pop(0)[0])
+        if red is not None:  # a stage is final once every product parked DURING it has been launched (any order: the
+            # repeated last layer waits one launch longer than the layers behind it, and must not hold their buckets back)
+            parked = [rec[3] for rec in pend]
+            still = []
+            for key, lo, hi in run.dw_ready_keys:
+                if any(lo <= i < hi for i in parked):
+                    still.append((key, lo, hi))
+                else:
+                    red.ready(key)
+            run.dw_ready_keys[:] = still
 
     def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
         """Backward of one layer execution.  dout: fp32 grad of its output.  Returns (dq_in, dkv_in) fp32 -- equal
@@ -948,6 +954,9 @@ class Engine:
         dqkv = torch.empty(N, 3 * H, dtype=BF16, device=self.dev)
         from .attn_bwd import disent_attn_bwd
 
+        if self.reducer is not None:  # ~0.35 ms without one-workgroup-per-CU GEMM tiles: where gradient collectives may start
+            self.reducer.window()
+
         pst = disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True)
         return dqkv, pst
 
@@ -992,7 +1001,7 @@ class Engine:
         reducer = self.reducer
 
         red = _Ready(self, run, reducer) if reducer is not None else None
-        run.dw_pending, run.dw_ready_keys, run.dw_count = [], [], 0
+        run.dw_pending, run.dw_ready_keys, run.dw_count, run.dw_stage_lo = [], [], 0, 0
         dq = torch.zeros(N, H, dtype=F32, device=dev)
         Vout = run.Vout
         Vp = _ru(Vout, 64)
@@ -1017,7 +1026,8 @@ class Engine:
             del dlog
 
         def stage_done(key):  # a stage's gradients are final once the adapter products parked in it have been launched
-            run.dw_ready_keys.append((key, run.dw_count))
+            run.dw_ready_keys.append((key, run.dw_stage_lo, run.dw_count))
+            run.dw_stage_lo = run.dw_count
             self._dw_flush(run, red)
 
         stage_done("head")

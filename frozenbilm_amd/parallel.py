@@ -2,31 +2,64 @@
 
 NEW capability relative to the reference, which never all-reduces gradients.  All trainable
 gradients live in ONE flat fp32 buffer ordered by backward completion (engine.flat_order); the backward pipeline calls
-``ready(bucket)`` as soon as a stage's gradients are final and the reducer launches an asynchronous SUM all-reduce on
-the contiguous slice [cursor, bucket_end) -- RCCL runs it on its own HIP stream, overlapped with the rest of backward.
-``finish()`` joins the collectives and scales by 1/world (DDP convention: mean of per-rank mean losses).  Frozen
-parameters never enter a bucket: 120.5 MB fp32 per step at DeBERTa-v2-XLarge, ~26 collectives of ~4.7 MB.
+``ready(bucket)`` as soon as a stage's gradients are final and the reducer all-reduces (asynchronous SUM, RCCL's own HIP
+stream) contiguous runs of ready stages; ``finish()`` joins the collectives and scales by 1/world (DDP convention: mean of
+per-rank mean losses).  Frozen parameters never enter a bucket: 120.5 MB fp32 per step at DeBERTa-v2-XLarge.
+
+WHERE in backward the collectives are launched is a knob (``overlap``), because of what the single-GPU measurements of this
+repo say about anything that holds CUs next to the large GEMMs: the 8-phase GEMM runs ONE workgroup
+per CU with all of its registers and LDS, so a tile cannot start on a CU on which a long-lived foreign workgroup sits -- and
+an RCCL ring kernel is exactly that, one workgroup per channel for the whole transfer.
+
+* ``"attention_windows"`` (default): ready stages are held until the engine announces a stretch of backward without such
+  tiles -- the attention backward of the next layer execution (~0.35 ms of latency-bound kernels with small workgroups that
+  share CUs gracefully) -- via ``window()``.  Overlapped with backward, as BASELINE's north star asks, but not on top of the
+  GEMMs.
+* ``"backward"``: launch at ``ready()``, whatever runs next (the round-1..3 behaviour).
+* ``"after"``: one collective after the last stage (``finish()``): no overlap, no interference; 120 MB is < 1 ms on xGMI.
+
+Stages may become ready out of order (the adapter weight gradients of a stage are final only when the group launch that
+carries them has been enqueued, and the repeated last layer waits one group longer): any maximal run of adjacent ready
+stages can leave, tiny ones (the 2H head LayerNorm) ride with a neighbour.  ``FBL_DP_OVERLAP`` overrides the default for A/B
+runs on a multi-GPU node (none was available to this build: the default is chosen by the reasoning above, not by measurement).
 """
 from __future__ import annotations
 
 import contextlib
-from typing import Dict, List, Optional
+import os
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+OVERLAP_MODES = ("attention_windows", "backward", "after")
+
 
 class GradReducer:
-    def __init__(self, flat_grad: torch.Tensor, bucket_ends: Dict[str, int], group=None, min_bucket_elems: int = 1 << 18):
+    def __init__(self, flat_grad: torch.Tensor, bucket_ends: Dict[str, int], group=None, min_bucket_elems: int = 1 << 18,
+                 overlap: Optional[str] = None):
         self.flat_grad = flat_grad
-        self.bucket_ends = dict(bucket_ends)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.min_bucket = min_bucket_elems
-        self.cursor = 0
+        self.overlap = overlap or os.environ.get("FBL_DP_OVERLAP") or "attention_windows"
+        if self.overlap not in OVERLAP_MODES:
+            raise ValueError(f"overlap must be one of {OVERLAP_MODES}, got {self.overlap!r}")
+        self._set_buckets(bucket_ends)
         self.pending: List = []
-        self.launched: List[tuple] = []
+        self.launched: List[Tuple[int, int]] = []
+        self.last_launched: List[Tuple[int, int]] = []
         self._held = False
+
+    def _set_buckets(self, bucket_ends: Dict[str, int]):
+        self.bucket_ends = dict(bucket_ends)
+        self.spans: Dict[str, Tuple[int, int]] = {}
+        lo = 0
+        for key, end in sorted(self.bucket_ends.items(), key=lambda kv: kv[1]):
+            self.spans[key] = (lo, end)
+            lo = end
+        self._ready: List[Tuple[int, int]] = []  # ready, not yet launched, sorted, non-overlapping
+        self._done: List[Tuple[int, int]] = []   # launched this step
 
     @classmethod
     def attach(cls, model, group=None, **kw) -> "GradReducer":
@@ -41,12 +74,19 @@ class GradReducer:
 
     def rebind(self, eng) -> None:
         """Point the reducer at a freshly built engine's flat gradient buffer and bucket boundaries."""
-        if self.pending or self.cursor:
+        if self.pending or self._ready or self._done:
             raise RuntimeError("GradReducer.rebind in the middle of a gradient exchange")
         self.flat_grad = eng.flat_grad
-        self.bucket_ends = dict(eng.bucket_ends)
+        self._set_buckets(eng.bucket_ends)
         self.launched = []
         eng.reducer = self
+
+    @property
+    def rccl_ranks(self) -> int:
+        """ranks the collectives of this reducer run over when the backend is nccl (= RCCL on ROCm), else 0"""
+        if not dist.is_initialized() or dist.get_backend(self.group) != "nccl":
+            return 0
+        return dist.get_world_size(self.group)
 
     @contextlib.contextmanager
     def accumulate(self):
@@ -60,32 +100,74 @@ class GradReducer:
             self._held = False
             self.finish()
 
+    # ------------------------------------------------------------------ called by the backward pipeline
     def ready(self, key: str):
+        """the gradients of stage `key` are final (any order)"""
         if self._held:
             return
-        end = self.bucket_ends.get(key)
-        if end is None or end <= self.cursor:
+        span = self.spans.get(key)
+        if span is None or span[1] <= span[0]:
             return
-        if end - self.cursor < self.min_bucket and end < self.flat_grad.numel():
-            return  # coalesce tiny buckets (e.g. the 2H head LayerNorm) into the next one
-        self._launch(end)
+        self._mark(span)
+        if self.overlap == "backward":
+            self._launch_ready(force=False)
 
-    def _launch(self, end: int):
+    def window(self):
+        """a stretch of backward without one-workgroup-per-CU GEMM tiles begins (engine: attention backward)"""
+        if not self._held and self.overlap == "attention_windows":
+            self._launch_ready(force=False)
+
+    # ------------------------------------------------------------------ internals
+    def _mark(self, span):
+        lo, hi = span
+        for a, b in self._ready + self._done:
+            if lo < b and a < hi:
+                return  # already signalled this step
+        self._ready.append((lo, hi))
+        self._ready.sort()
+        merged = [self._ready[0]]
+        for a, b in self._ready[1:]:
+            if a == merged[-1][1]:
+                merged[-1] = (merged[-1][0], b)
+            else:
+                merged.append((a, b))
+        self._ready = merged
+
+    def _launch_ready(self, force: bool):
+        keep = []
+        for lo, hi in self._ready:
+            if not force and hi - lo < self.min_bucket and hi < self.flat_grad.numel():
+                keep.append((lo, hi))  # tiny run: waits for a neighbour (or for finish)
+                continue
+            self._launch(lo, hi)
+        self._ready = keep
+
+    def _launch(self, lo: int, hi: int):
         if self.world > 1:
-            sl = self.flat_grad[self.cursor:end]
-            self.pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self.launched.append((self.cursor, end))
-        self.cursor = end
+            self.pending.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((lo, hi))
+        self._done.append((lo, hi))
 
     def finish(self):
         if self._held:
             return
-        if self.cursor < self.flat_grad.numel():
-            self._launch(self.flat_grad.numel())
+        # whatever was never signalled (or was held back) leaves now, as maximal contiguous runs
+        n = self.flat_grad.numel()
+        covered = sorted(self._done + self._ready)
+        cur, gaps = 0, []
+        for a, b in covered:
+            if a > cur:
+                gaps.append((cur, a))
+            cur = max(cur, b)
+        if cur < n:
+            gaps.append((cur, n))
+        for g in gaps:
+            self._mark(g)
+        self._launch_ready(force=True)
         for w in self.pending:
             w.wait()
         self.pending.clear()
         if self.world > 1:
             self.flat_grad.mul_(1.0 / self.world)
-        self.cursor = 0
         self.last_launched, self.launched = self.launched, []
+        self._done = []

@@ -1,6 +1,9 @@
 """One rank of the two-rank data-parallel check of the HIP engine (launched by tests/test_gpu_model.py).
 
-    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv[1] = output file (rank 0 writes it).
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv[1] = output file (rank 0 writes it),
+    argv[2] = GradReducer.overlap mode (optional), argv[3] = "tiny" (default) or "xl4": the true xlarge dimensions
+    (H = 1536, 24 heads, I = 6144, 192-wide adapters) with 4 layers, adapter gradients leaving in groups of 4 so that the
+    stage buckets become final out of order under a real collective.
 
 Backend: nccl (= RCCL) with one GPU per rank when the box has at least WORLD_SIZE GPUs, otherwise gloo with every rank on
 cuda:0 -- the same engine / GradReducer code path either way (bucketed async all-reduce of the flat trainable gradient
@@ -18,6 +21,9 @@ import torch.distributed as dist
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    xl = len(sys.argv) > 3 and sys.argv[3] == "xl4"
+    if xl:
+        os.environ["FBL_DW_GROUP"] = "4"  # read at engine construction: 4 adapters per gradient launch
     multi = torch.cuda.device_count() >= world
     dev = torch.device("cuda", rank if multi else 0)
     torch.cuda.set_device(dev)
@@ -28,12 +34,17 @@ def main():
     from tests.golden.make_goldens import _tiny_cfg, synth_batch
     from tests.test_gpu_model import build
 
-    cfg = _tiny_cfg()
-    m = build(cfg, O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1))  # eval mode: dropout off, gradients on
+    if xl:
+        cfg = O.OracleConfig()
+        cfg.num_hidden_layers, cfg.vocab_size = 4, 4096
+    else:
+        cfg = _tiny_cfg()
+    m = build(cfg, O.synth_params(cfg, seed=41, std=0.02 if xl else 0.05, ln_jitter=0.1))  # eval mode: dropout off, gradients on
     m.to(dev)
-    red = GradReducer.attach(m, min_bucket_elems=1 << 10)  # small buckets: several collectives in flight during backward
+    # small buckets: several collectives in flight during backward; argv[2] = where they are launched (GradReducer.overlap)
+    red = GradReducer.attach(m, min_bucket_elems=1 << 10, overlap=sys.argv[2] if len(sys.argv) > 2 else None)
     per = 2
-    batch = synth_batch(cfg, B=per * world, L=60, seed=9)
+    batch = synth_batch(cfg, B=per * world, L=96 if xl else 60, seed=9)
     mine = {k: v[rank * per:(rank + 1) * per].to(dev) for k, v in batch.items()}
     losses = []
     for _ in range(2):  # two steps: the reducer's cursor / bucket bookkeeping must reset between them
@@ -44,6 +55,10 @@ def main():
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
     n_coll = len(red.last_launched)
+    spans = sorted(red.last_launched)
+    covers = spans[0][0] == 0 and spans[-1][1] == red.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    print(f"[dp_worker] rank {rank}/{world}: backend {dist.get_backend()}, RCCL saw {red.rccl_ranks} ranks, overlap "
+          f"{red.overlap}, {n_coll} collectives per step, launch order {red.last_launched[:6]}...", flush=True)
     # every rank must hold the same reduced gradients
     flat = torch.cat([g.reshape(-1) for g in grads.values()]).to(dev)
     ref = flat.clone()
@@ -53,6 +68,7 @@ def main():
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
         torch.save({"grads": grads, "losses": losses, "backend": dist.get_backend(), "collectives": n_coll,
+                    "rccl_ranks": red.rccl_ranks, "overlap": red.overlap, "covers": covers, "launch_order": list(red.last_launched),
                     "ranks_agree": bool(ok.item() == 1.0), "world": world}, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()

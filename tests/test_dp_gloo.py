@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
         flat = torch.randn(n, generator=g)
         mine = flat.clone()
         ends = {"head": 16, "layer2": 1800, "layer1": 3600, "conv": 3616, "layer0": 4900, "relln": 4916, "emb": n}
-        red = GradReducer(flat, ends, min_bucket_elems=64)
+        red = GradReducer(flat, ends, min_bucket_elems=64, overlap="backward")
         for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
             red.ready(key)
         red.finish()
@@ -38,13 +38,29 @@ def _worker(rank, world, port, q):
         # buckets: contiguous, ordered, covering; tiny ones coalesced into the next
         spans = red.last_launched
         ok &= spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        ok &= all(e - s >= 64 for s, e in spans)
-        # second step reuses the reducer
+        ok &= all(e - s >= 64 for s, e in spans) and len(spans) >= 3
+        # second step reuses the reducer; stages become final OUT of order (the repeated last layer's adapters leave with a
+        # later group launch than the layers behind it): runs of adjacent ready stages leave, nothing twice, everything once
         flat.copy_(mine)
-        for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
+        for key in ("head", "layer1", "conv", "layer2", "relln", "layer0", "emb"):
             red.ready(key)
         red.finish()
         ok &= torch.allclose(flat, expect, atol=1e-6)
+        sp = sorted(red.last_launched)
+        ok &= sp[0][0] == 0 and sp[-1][1] == n and all(a[1] == b[0] for a, b in zip(sp, sp[1:]))
+        # "attention_windows": ready stages are held until the engine opens a window; "after": one collective at the end
+        for mode in ("attention_windows", "after"):
+            flat.copy_(mine)
+            rw = GradReducer(flat, ends, min_bucket_elems=64, overlap=mode)
+            rw.ready("head"); rw.ready("layer2")
+            ok &= not rw.launched
+            rw.window()
+            ok &= (rw.launched == [(0, 1800)]) if mode == "attention_windows" else (not rw.launched)
+            for key in ("layer1", "conv", "layer0", "relln", "emb"):
+                rw.ready(key)
+            rw.finish()
+            ok &= torch.allclose(flat, expect, atol=1e-6)
+            ok &= sorted(rw.last_launched) == ([(0, 1800), (1800, n)] if mode == "attention_windows" else [(0, n)])
         # several backward passes feeding one step (mc.py): nothing leaves before the context closes
         flat.copy_(mine)
         with red.accumulate():
@@ -119,7 +135,7 @@ def test_single_process_is_identity():
     from frozenbilm_amd.util import dist as D
 
     flat = torch.arange(10.0)
-    red = GradReducer(flat, {"a": 4, "b": 10}, min_bucket_elems=1)
+    red = GradReducer(flat, {"a": 4, "b": 10}, min_bucket_elems=1, overlap="backward")
     red.ready("a"); red.ready("b"); red.finish()
     assert torch.equal(flat, torch.arange(10.0)) and red.last_launched == [(0, 4), (4, 10)]
     d = {"x": torch.tensor(1.0)}

@@ -628,7 +628,7 @@ def test_grad_reducer_on_the_hip_engine_nccl():
         created = True
     try:
         m = build(cfg, P)
-        red = GradReducer.attach(m, min_bucket_elems=1)
+        red = GradReducer.attach(m, min_bucket_elems=1, overlap="backward")
         eng0 = m.engine()
         m.load_state_dict(P, strict=False)  # invalidates the engine AFTER the reducer was attached
         m.to(DEV)
@@ -640,7 +640,7 @@ def test_grad_reducer_on_the_hip_engine_nccl():
         for n, p in m.named_parameters():
             if p.requires_grad:
                 assert torch.allclose(p.grad, want[n] * 0.5, rtol=1e-6, atol=0), n  # SUM over 1 rank, then / world(=2)
-        spans = red.last_launched
+        spans = sorted(red.last_launched)  # (stages may become final out of order: the repeated last layer)
         assert spans[0][0] == 0 and spans[-1][1] == eng.flat_grad.numel()
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         ends = set(eng.bucket_ends.values())
@@ -663,12 +663,7 @@ def test_grad_reducer_on_the_hip_engine_nccl():
             dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path):
-    """Two processes, one rank each, over RCCL (nccl backend, one GPU per rank) when the box has two GPUs and over gloo
-    with both ranks on cuda:0 otherwise: the gradients left in p.grad after backward + GradReducer.finish() equal the
-    single-process gradients of the same four samples under the DDP loss convention (mean over ranks of the per-rank mean
-    loss) -- same kernels, same inputs, so to fp32 rounding -- on every rank, over two consecutive steps, with several
-    bucket collectives launched from inside the backward pipeline."""
+def _run_two_ranks(tmp_path, overlap, config):
     import os
     import socket
     import subprocess
@@ -678,42 +673,141 @@ def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
-    out_file = str(tmp_path / "dp.pt")
+    out_file = str(tmp_path / f"dp_{overlap}_{config}.pt")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), out_file], env=env, cwd=root,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), out_file, overlap, config],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p_ in procs:
         try:
-            o, _ = p_.communicate(timeout=300)
+            o, _ = p_.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             p_.kill()
             o, _ = p_.communicate()
         logs.append(o)
     assert all(p_.returncode == 0 for p_ in procs), "\n".join(logs)
-    got = torch.load(out_file)
-    assert got["ranks_agree"] and got["world"] == world and got["collectives"] >= 3, {k: got[k] for k in ("ranks_agree", "collectives")}
-    print(f"backend {got['backend']}, {got['collectives']} bucket collectives per step")
-    # single process: the two half batches, gradients accumulated and averaged (DDP convention)
-    cfg = _tiny_cfg()
-    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    print("\n".join(l for lg in logs for l in lg.splitlines() if "[dp_worker]" in l))
+    return torch.load(out_file)
+
+
+def _single_process_reference(cfg, P, L):
     m = build(cfg, P)
-    batch = synth_batch(cfg, B=4, L=60, seed=9)
+    batch = synth_batch(cfg, B=4, L=L, seed=9)
     m.zero_grad(set_to_none=False)
     losses = []
-    for r in range(world):
+    for r in range(2):
         out = m(**{k: v[2 * r:2 * r + 2].to(DEV) for k, v in batch.items()})
         out.loss.backward()
         losses.append(out.loss.item())
+    return {n: p.grad.float().cpu() / 2 for n, p in m.named_parameters() if p.requires_grad}, losses
+
+
+@pytest.mark.parametrize("overlap", ["backward", "attention_windows", "after"])
+def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path, overlap):
+    """Two processes, one rank each, over RCCL (nccl backend, one GPU per rank) when the box has two GPUs and over gloo
+    with both ranks on cuda:0 otherwise: the gradients left in p.grad after backward + GradReducer.finish() equal the
+    single-process gradients of the same four samples under the DDP loss convention (mean over ranks of the per-rank mean
+    loss) -- same kernels, same inputs, so to fp32 rounding -- on every rank, over two consecutive steps, for each
+    placement of the collectives (GradReducer.overlap): from inside the backward pipeline at every final stage, only inside
+    the attention-backward windows, or once after backward."""
+    got = _run_two_ranks(tmp_path, overlap, "tiny")
+    assert got["ranks_agree"] and got["world"] == 2 and got["covers"] and got["overlap"] == overlap
+    assert (got["collectives"] >= 3) if overlap != "after" else (got["collectives"] == 1), got["launch_order"]
+    print(f"backend {got['backend']} (RCCL ranks: {got['rccl_ranks']}), {got['collectives']} bucket collectives per step")
+    cfg = _tiny_cfg()
+    want, losses = _single_process_reference(cfg, O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1), 60)
     assert abs(got["losses"][0] - losses[0]) < 1e-6 and abs(got["losses"][1] - losses[0]) < 1e-6  # rank 0's own loss, both steps
-    worst = 0.0
-    for n, p in m.named_parameters():
-        if p.requires_grad:
-            ref = p.grad.float().cpu() / world
-            worst = max(worst, _rel_fro(got["grads"][n], ref))
+    worst = max(_rel_fro(got["grads"][n], want[n]) for n in want)
     print(f"worst relative difference reduced-vs-single-process: {worst:.2e}")
     assert worst < 1e-5, worst
+
+
+@pytest.mark.slow
+def test_two_rank_data_parallel_at_xlarge_dimensions(tmp_path):
+    """The same check at the true xlarge dimensions (H = 1536, 24 heads, I = 6144, 192-wide adapters; 4 layers, B = 2 per
+    rank) with the adapter gradients leaving in groups of 4: the stage buckets become final OUT of order (the repeated last
+    layer waits for the second group launch, the layers behind it do not), the collectives start in the attention-backward
+    windows -- the default placement -- and the flat buffer is still covered exactly once."""
+    got = _run_two_ranks(tmp_path, "attention_windows", "xl4")
+    assert got["ranks_agree"] and got["covers"] and got["collectives"] >= 2, got["launch_order"]
+    order = got["launch_order"]
+    assert order != sorted(order), f"expected an out-of-order bucket launch, got {order}"
+    print(f"backend {got['backend']} (RCCL ranks: {got['rccl_ranks']}), launch order {order}")
+    cfg = O.OracleConfig()
+    cfg.num_hidden_layers, cfg.vocab_size = 4, 4096
+    import os
+    os.environ["FBL_DW_GROUP"] = "4"
+    try:
+        want, _ = _single_process_reference(cfg, O.synth_params(cfg, seed=41, std=0.02, ln_jitter=0.1), 96)
+    finally:
+        del os.environ["FBL_DW_GROUP"]
+    worst = max(_rel_fro(got["grads"][n], want[n]) for n in want)
+    print(f"worst relative difference reduced-vs-single-process at xlarge dims: {worst:.2e}")
+    assert worst < 1e-5, worst
+
+
+def test_operands_follow_hidden_parameter_writes_unless_frozen():
+    """an inference forward after a write the engine cannot see (through `.data`) must run on the new weights --
+    operands are rebuilt on every forward; only inside `model.weights_frozen()` (the evaluate loops) is the rebuild skipped,
+    and there FusedAdam.step / in-place updates through the parameter object are still seen."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P, train=False)
+    batch = to_dev(synth_batch(cfg, B=2, L=24, seed=3))
+    name = "deberta.encoder.layer.1.output.adapter.up.weight"
+    p = m.get_param(name)
+    with torch.no_grad():
+        l0 = m(**batch).loss.item()
+        p.data.mul_(3.0)  # hidden write: neither params_version nor the autograd version counter moves
+        l1 = m(**batch).loss.item()
+        assert abs(l1 - l0) > 1e-4, "the forward still ran on the old adapter weights"
+        with m.weights_frozen():
+            l2 = m(**batch).loss.item()  # first forward in the scope rebuilds
+            assert l2 == l1
+            p.data.mul_(1.0 / 3.0)  # breaks the promise: the scope keeps the packed operands
+            assert m(**batch).loss.item() == l1
+            p.mul_(1.0)  # a write through the parameter object bumps its version counter: seen
+            l3 = m(**batch).loss.item()
+            assert abs(l3 - l0) < 1e-6
+        assert abs(m(**batch).loss.item() - l0) < 1e-6
+
+
+def test_delayed_loss_check_gives_the_same_epoch_statistics():
+    """`args.delayed_loss_check`: the loss of step i is logged when step i+1 calls (asynchronous copy to pinned memory);
+    the epoch's averaged statistics and the parameter updates equal the reference-order loop's."""
+    import types
+
+    from frozenbilm_amd import main as P_main
+    from frozenbilm_amd.optim import FusedAdam
+    from tests.downstream_fixtures import ListLoader, StubTokenizer
+
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=43, std=0.05, ln_jitter=0.1)
+    tok = StubTokenizer(cfg.vocab_size)
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for i in range(4):
+        ids = torch.randint(5, cfg.vocab_size, (3, 20), generator=g)
+        batches.append(dict(video=torch.randn(3, cfg.max_feats, cfg.features_dim, generator=g), video_len=torch.tensor([cfg.max_feats, 2, 1]),
+                            text=[" ".join(str(int(t)) for t in row) for row in ids], qid=[3 * i, 3 * i + 1, 3 * i + 2]))
+    stats_out, finals = [], []
+    for delayed in (False, True):
+        m = build(cfg, P, train=True)
+        opt = FusedAdam(m, lr=1e-3)
+        args = types.SimpleNamespace(max_tokens=64, mlm_prob=0.15, print_freq=100, epochs=1, lr=1e-3, schedule="",
+                                     fraction_warmup_steps=0.1, delayed_loss_check=delayed)
+        torch.manual_seed(1234)  # mask_tokens draws from the default CPU generator
+        m.step_seed = 0
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            st = P_main.train_one_epoch(m, tok, ListLoader(batches), opt, torch.device(DEV), 0, args, max_norm=1.0)
+        stats_out.append(st)
+        finals.append(m.get_param("deberta.embeddings.linear_video.weight").detach().clone())
+    assert set(stats_out[0]) == set(stats_out[1])
+    for k in stats_out[0]:
+        assert abs(stats_out[0][k] - stats_out[1][k]) < 1e-6, (k, stats_out)
+    assert torch.equal(finals[0], finals[1])

@@ -138,7 +138,8 @@ def test_oracle_xlarge_golden(golden):
 def test_adapter_gradient_grouping_policy(monkeypatch):
     """Engine._dw_flush (host logic, no GPU): parked adapter-gradient products leave in launches of `dw_group` distinct
     adapters, an adapter executed twice (the last layer, enhanced mask decoder) is split over two launches, and the gradient
-    reducer hears about a stage only when every product parked before the stage's end has been launched -- in stage order."""
+    reducer hears about a stage as soon as every product parked DURING that stage has been launched -- the repeated last
+    layer's stage one launch later than the layers behind it, which do not wait for it."""
     from frozenbilm_amd import engine as E
 
     launches = []
@@ -147,7 +148,7 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
     names = lambda li: [f"layer.{li}.a1", f"layer.{li}.a2"]
     G = {n + sfx: n for li in range(nL) for n in names(li) for sfx in (".up.weight", ".down.weight", ".down.bias")}
     eng = types.SimpleNamespace(dw_group=6, G=G)
-    run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0)
+    run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0, dw_stage_lo=0)
     ready = []
     red = types.SimpleNamespace(ready=ready.append)
 
@@ -157,7 +158,8 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
             run.dw_count += 1
 
     def stage_done(key):
-        run.dw_ready_keys.append((key, run.dw_count))
+        run.dw_ready_keys.append((key, run.dw_stage_lo, run.dw_count))
+        run.dw_stage_lo = run.dw_count
         E.Engine._dw_flush(eng, run, red)
 
     stage_done("head")
@@ -169,11 +171,13 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
         park(li)
         stage_done(f"layer{li}")
         if li == 5:  # six distinct adapters pending: the first launch leaves, the repeated pair stays behind ...
-            assert launches == [names(7) + names(6) + names(5)] and ready == ["head"]  # ... and with it layer 7's bucket
+            assert launches == [names(7) + names(6) + names(5)]
+            assert ready == ["head", "layer6", "layer5"]  # ... and with it layer 7's bucket only
     E.Engine._dw_flush(eng, run, red, force=True)
     assert not run.dw_pending and not run.dw_ready_keys
     assert all(len(set(l)) == len(l) <= 6 for l in launches)  # an adapter at most once per launch
     flat = [n for l in launches for n in l]
     assert sorted(flat) == sorted(names(nL - 1) * 2 + [n for li in range(nL - 1) for n in names(li)])
     assert launches[1][:2] == names(7)  # the deferred pair leads the next launch
-    assert ready == ["head"] + [f"layer{li}" for li in range(nL - 1, -1, -1)]
+    assert sorted(ready) == sorted(["head"] + [f"layer{li}" for li in range(nL)]) and len(ready) == nL + 1
+    assert ready.index("layer7") > ready.index("layer5")  # final only with the second launch
