@@ -343,7 +343,54 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ---- attention probabilities on request (output_attentions=True: model/deberta.py:789-818 return_att, :544-560).
+// The fused kernel never materialises P; this plain kernel does, for callers that ask: one workgroup per (sample, head,
+// query row), thread j-strided over the keys, P[i,j] = exp(scale*(Q_i.K_j + Q_i.PK[idx] + K_j.PQ[idx]) - lse_i) with the
+// log-sum-exp the fused forward stored -- 0 for masked pairs and for masked query rows (XSoftmax).  Not on the hot path.
+__global__ __launch_bounds__(128) void attn_probs_kernel(const bf16* q, const bf16* k, long ldq, const bf16* pk, const bf16* pq,
+                                                         long ldp, const int16_t* relidx, const int32_t* mask, const float* lse,
+                                                         float scale, float* probs, int B, int S, int nh) {
+  __shared__ float qs[64];
+  const int i = blockIdx.x % S, h = (blockIdx.x / S) % nh, b = blockIdx.x / (S * nh);
+  const long row = (long)b * S + i;
+  if (threadIdx.x < 64) qs[threadIdx.x] = bf2f(q[row * ldq + h * 64 + threadIdx.x]);
+  __syncthreads();
+  const bool qvalid = mask[row] != 0;
+  const float l = lse[((long)b * nh + h) * S + i];
+  float* out = probs + (((long)b * nh + h) * S + i) * S;
+  for (int j = threadIdx.x; j < S; j += blockDim.x) {
+    float p = 0.f;
+    if (qvalid && mask[(long)b * S + j] != 0) {
+      const int r = relidx[i - j + S - 1];
+      const bf16* kj = k + ((long)b * S + j) * ldq + h * 64;
+      const bf16* pkr = pk + (long)r * ldp + h * 64;
+      const bf16* pqr = pq + (long)r * ldp + h * 64;
+      float s = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 64; ++d) {
+        const float kd = bf2f(kj[d]);
+        s += qs[d] * (kd + bf2f(pkr[d])) + kd * bf2f(pqr[d]);
+      }
+      p = __expf(s * scale - l);
+    }
+    out[j] = p;
+  }
+}
+
 }  // namespace
+
+extern "C" int fbl_disent_attn_probs(const void* q, const void* k, int64_t ldq, const void* pk, const void* pq, int64_t ldp,
+                                     const int16_t* relidx, const int32_t* mask, const float* lse, float scale,
+                                     float* probs, int B, int S, int nh, void* stream) {
+  if (S < 1 || S > 512) return FBL_ERR_SHAPE;
+  if (!q || !k || !pk || !pq || !relidx || !mask || !lse || !probs) return FBL_ERR_ARG;
+  if (B <= 0 || nh <= 0) return 0;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * nh * S)), dim3(128), 0, (hipStream_t)stream, (const bf16*)q,
+                     (const bf16*)k, (long)ldq, (const bf16*)pk, (const bf16*)pq, (long)ldp, relidx, mask, lse, scale, probs, B, S,
+                     nh);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                    const void* pk, const void* pq, int64_t ldp,
@@ -360,20 +407,16 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
   a.dbg = dbg;
   attn_debug_init();
   const int smem_bytes = sm_total(Sp);
-  // three workgroups per CU (<= 168 VGPRs).  Variant 0: no register prefetch of the next key tile -- the other two
-  // workgroups of the CU cover the load (measured 88.6 us vs 97.2 with the prefetch, whose registers spill); variant 1
-  // (debug builds) keeps the prefetch
-  static const int var = FBL_ENV_INT("FBL_ATTN_OCC", 0) == 1 ? 1 : 0;
-  using KFn = void (*)(AttnArgs);
-  static const KFn fns[2] = {attn_fwd_kernel<3, false>, attn_fwd_kernel<3, false>};
-  static int attr_bytes[2] = {0, 0};
-  if (smem_bytes > attr_bytes[var]) {
-    hipError_t e = hipFuncSetAttribute((const void*)fns[var], hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+  // three workgroups per CU (<= 168 VGPRs), no register prefetch of the next key tile: the other two workgroups of the CU
+  // cover the load (measured 88.6 us vs 97.2 with the prefetch, whose registers spill)
+  static int attr_bytes = 0;
+  if (smem_bytes > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
-    attr_bytes[var] = smem_bytes;
+    attr_bytes = smem_bytes;
   }
   dim3 grid((unsigned)((S + 63) / 64) * nh * B);
-  hipLaunchKernelGGL(fns[var], grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<3, false>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -409,7 +409,7 @@ class Engine:
         return ent["upT"], ent["downT"]
 
     # ------------------------------------------------------------------ public entry
-    def run(self, input_ids, attention_mask, video, video_mask, labels, mlm, want_hidden, logit_rows=None):
+    def run(self, input_ids, attention_mask, video, video_mask, labels, mlm, want_hidden, logit_rows=None, want_attn=False):
         m = self.m
         train = m.training
         need_grad = torch.is_grad_enabled() and any(self.named[n].requires_grad for n in self.order)
@@ -449,6 +449,10 @@ class Engine:
                   p_att=self.cfg.attention_probs_dropout_prob if train else 0.0,
                   p_ad=m.adapter_dropout if train else 0.0)
         run.mask = mask.view(-1)
+        run.want_attn = bool(want_attn)
+        if want_attn and train and run.p_att > 0:
+            raise NotImplementedError("output_attentions=True is served in eval mode (the probabilities of a training forward "
+                                      "carry the attention dropout mask, which the fused kernel regenerates instead of storing)")
         run.labels = full_labels
         run.rows = rows_labelled if full_labels is not None else None
         self._refresh_if_stale(need_grad)  # bf16 operands / composed adapter rows of the trainable parameters
@@ -457,16 +461,20 @@ class Engine:
             if need_grad or full_labels is not None:
                 raise RuntimeError("logit_rows is an inference-time option (no labels, no gradient bookkeeping)")
             run.logit_rows = logit_rows.to(self.dev).to(torch.int32).contiguous().view(-1)
-        logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden)
+        logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden or want_attn)
         Vout = self.n_ans if use_ans else self.V
         if logit_rows is not None:
             res = {"logits": logits[:, :Vout], "loss": None, "run": run}
             if want_hidden:
                 res["hidden_states"] = run.hidden_out
+            if want_attn:
+                res["attentions"] = tuple(run.attn_out)
             return res
         res = {"logits": logits.view(B, S, -1)[:, :, :Vout] if logits is not None else None, "loss": None, "run": run}
         if want_hidden:
             res["hidden_states"] = run.hidden_out
+        if want_attn:
+            res["attentions"] = tuple(run.attn_out)
         if need_grad and res["logits"] is not None:
             # one autograd node for the whole model; both outputs are differentiable: the loss (MLM training,
             # main.py:67-84) and the logits (downstream fine-tuning computes its own loss on them, videoqa.py:66-83,
@@ -600,6 +608,13 @@ class Engine:
         L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], qkv[:N, 2 * H:], pk, pq, self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
                           seed=sv.seed_att, klen=run.klen, border=run.border, lin=self.lin_span)
+        if getattr(run, "want_attn", False) and q is None:
+            # output_attentions=True: the encoder layers' probabilities (model/deberta.py:544-560; the enhanced-mask-decoder
+            # passes are called with return_att=False, :1395-1408), materialised by a plain kernel from the stored lse
+            probs = torch.empty(B, nh, S, S, dtype=F32, device=dev)
+            L.disent_attn_probs(qkv[:N, :H], qkv[:N, H:2 * H], pk, pq, self.relidx(S), run.mask_i32, lse,
+                                1.0 / math.sqrt(64 * 3), probs, B, S, nh)
+            run.attn_out.append(probs)
         # attention output: dense -> adapter -> dropout -> LN(. + residual)   (:254-260)
         ad = self.ad[li]
         p = f"deberta.encoder.layer.{li}"
@@ -1159,6 +1174,8 @@ class Run:
     mask: torch.Tensor = None
     labels: torch.Tensor = None
     hidden_out: tuple = None
+    want_attn: bool = False
+    attn_out: list = field(default_factory=list)
     seed_emb: int = 0
     seed_conv: int = 0
 

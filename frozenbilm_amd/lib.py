@@ -52,6 +52,7 @@ SIGNATURES = {
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
     "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
                                  _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -474,6 +475,17 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
                                     _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _p(ctx), ldo,
                                     _p(lse), B, S, Sp, nh, span2, int(lin), _stream()), "fbl_disent_attn_fwd")
+
+
+def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
+    """probs[B,nh,S,S] (fp32) = the attention probabilities behind fbl_disent_attn_fwd's ctx (from its lse); eval mode"""
+    for t, n in ((q, "q"), (k, "k"), (pk, "pk"), (pq, "pq")):
+        _req(t, torch.bfloat16, n)
+    _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask"); _req(lse, torch.float32, "lse"); _req(probs, torch.float32, "probs")
+    ldq, ldp = _rows2d(q, "q"), _rows2d(pk, "pk")
+    assert _rows2d(k, "k") == ldq and _rows2d(pq, "pq") == ldp and probs.is_contiguous() and probs.numel() == B * nh * S * S
+    _chk(load().fbl_disent_attn_probs(_p(q), _p(k), ldq, _p(pk), _p(pq), ldp, _p(relidx), _p(mask), _p(lse), float(scale),
+                                      _p(probs), B, S, nh, _stream()), "fbl_disent_attn_probs")
 
 
 def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2):

@@ -445,22 +445,23 @@ class DebertaV2ForMaskedLM(nn.Module):
             if inputs_embeds is not None:
                 raise NotImplementedError("inputs_embeds is not on the FrozenBiLM hot path")
             raise ValueError("You have to specify either input_ids or inputs_embeds")
-        if output_attentions:
-            raise NotImplementedError("attention probabilities are never materialised by the fused kernel")
         eng = self.engine()
         if (self.inference_graphs and logit_rows is not None and labels is None and not output_hidden_states
-                and not self.training and not torch.is_grad_enabled()):
+                and not output_attentions and not self.training and not torch.is_grad_enabled()):
             logits = self._graph_forward(eng, input_ids, attention_mask, video, video_mask, mlm, logit_rows)
             if logits is not None:
                 out = MaskedLMOutput(loss=None, logits=logits, hidden_states=None, attentions=None)
                 return out if return_dict is not False else (logits,)
-        res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states, logit_rows=logit_rows)
+        # output_attentions=True (model/deberta.py:1414-1427, :544-560): the fused attention kernel never materialises its
+        # probabilities; on request a plain kernel rebuilds them per encoder layer from the stored log-sum-exp (eval mode)
+        res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states, logit_rows=logit_rows,
+                      want_attn=bool(output_attentions))
         out = MaskedLMOutput(loss=res["loss"], logits=res["logits"], hidden_states=res.get("hidden_states"),
-                             attentions=None)
+                             attentions=res.get("attentions"))
         run = res.get("run")
         out.__dict__["_run"] = run  # (tests read the saved bottleneck activations through this)
         if run is not None and getattr(run, "logits_pending", False):
             out.__dict__["_fill"] = lambda: eng.fill_logits(run)
         if return_dict is False:
-            return tuple(v for v in (out["loss"], out["logits"], out["hidden_states"]) if v is not None)
+            return tuple(v for v in (out["loss"], out["logits"], out["hidden_states"], out["attentions"]) if v is not None)
         return out

@@ -238,6 +238,14 @@ int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
                         uint64_t seed, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
                         int lin_span, void* stream);
 
+/* The attention probabilities of fbl_disent_attn_fwd, materialised on request (output_attentions=True; never on the hot
+ * path): probs[b, h, i, j] fp32 [B, nh, S, S] = exp(score[i,j] - lse[b,h,i]) with the lse the fused forward stored, exactly 0
+ * for masked pairs and masked query rows; q/k/pk/pq/relidx/mask as in fbl_disent_attn_fwd (eval mode: no dropout).
+ * ref: model/deberta.py:789-818 (return_att), :544-560 (the encoder's attentions tuple). */
+int fbl_disent_attn_probs(const void* q, const void* k, int64_t ldq, const void* pk, const void* pq, int64_t ldp,
+                          const int16_t* relidx, const int32_t* mask, const float* lse, float scale, float* probs, int B,
+                          int S, int nh, void* stream);
+
 /* Backward of fbl_disent_attn_fwd, three launches (ref: autograd of model/deberta.py:717-947, XSoftmax.backward
  * :134-138, XDropout.backward :185-190):
  *  fbl_attn_rowdot:            Dv[b,h,i] = dO_i . O_i  (per head).

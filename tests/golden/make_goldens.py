@@ -199,6 +199,64 @@ def g3_attention(deberta):
     npz("G3_attention", seed=np.array([3]), **out)
 
 
+def g3b_attention_backward(deberta):
+    """Backward of DisentangledSelfAttention (eval, d=64, 2 heads, S=37 and 266, padded rows, with and without
+    query_states; same modules / seeds / inputs as G3): for a seeded upstream gradient dy of the context layer, the
+    reference's gradients w.r.t. the OUTPUTS of query_proj / key_proj / value_proj on the token rows (what the HIP backward
+    kernels return as dq, dk, dv) and on the relative-position table rows (dPQ, dPK), captured with forward hooks; plus the
+    end-to-end input gradients (hidden_states, query_states, rel_embeddings).  S=266: token-row tensors stored every third
+    row, fp16 (file size)."""
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    enc = m.deberta.encoder
+    att = enc.layer[1].attention.self
+    caught = {"q": [], "k": [], "v": []}
+    hooks = []
+    for key, mod in (("q", att.query_proj), ("k", att.key_proj), ("v", att.value_proj)):
+        def hook(_m, _i, o, key=key):
+            o.retain_grad()
+            caught[key].append(o)
+        hooks.append(mod.register_forward_hook(hook))
+    out = {}
+    for S in (37, 266):
+        g = torch.Generator().manual_seed(100 + S)
+        B = 2
+        hidden = torch.randn(B, S, cfg.hidden_size, generator=g)
+        qs = torch.randn(B, S, cfg.hidden_size, generator=g)
+        mask = torch.ones(B, S, dtype=torch.long)
+        mask[0, S - 5:] = 0
+        mask[1, 3:6] = 0
+        dy = torch.randn(B, S, cfg.hidden_size, generator=torch.Generator().manual_seed(500 + S))
+        for tag, use_q in (("", False), ("q", True)):
+            for v in caught.values():
+                v.clear()
+            h = hidden.clone().requires_grad_(True)
+            q_in = qs.clone().requires_grad_(True) if use_q else None
+            with torch.no_grad():
+                m4 = enc.get_attention_mask(mask)
+                rel = enc.get_rel_pos(hidden)
+            remb = enc.get_rel_embedding().detach().clone().requires_grad_(True)
+            y = att(h, m4, False, query_states=q_in, relative_pos=rel, rel_embeddings=remb)
+            y.backward(dy)
+            # call order (model/deberta.py:757-765, 847-853): query_proj(tokens), key_proj(tokens), value_proj(tokens),
+            # query_proj(rel_embeddings), key_proj(rel_embeddings)
+            assert [len(caught[k]) for k in "qkv"] == [2, 2, 1]
+            sl = (lambda t: t) if S == 37 else (lambda t: t[:, ::3].half())
+            cv = (lambda t: t) if S == 37 else (lambda t: t.half())
+            out.update({f"dq{tag}_{S}": sl(caught["q"][0].grad), f"dk{tag}_{S}": sl(caught["k"][0].grad),
+                        f"dv{tag}_{S}": sl(caught["v"][0].grad), f"dpq{tag}_{S}": cv(caught["q"][1].grad[0]),
+                        f"dpk{tag}_{S}": cv(caught["k"][1].grad[0]), f"dhidden{tag}_{S}": sl(h.grad), f"drel{tag}_{S}": cv(remb.grad)})
+            if use_q:
+                out[f"dqs_{S}"] = sl(q_in.grad)
+        out[f"dy_{S}"] = dy
+    for hk in hooks:
+        hk.remove()
+    npz("G3b_attention_backward", seed=np.array([3]), **out)
+
+
 def g4_layer_conv(deberta):
     from oracle.deberta_oracle import synth_params
 
@@ -248,6 +306,22 @@ def g5_tiny_model(deberta):
     with torch.no_grad():
         o2 = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"])
     npz("G5b_tiny_textonly", logits=o2.logits)
+
+
+def g5c_attentions(deberta):
+    """The tiny model of G5 (same weights, same batch) with output_attentions=True: the reference's `attentions` tuple -- one
+    [B, heads, S, S] probability tensor per encoder layer (model/deberta.py:544-560) -- plus logits to tie the two calls."""
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    batch = synth_batch(cfg, B=3, L=27, seed=55)
+    with torch.no_grad():
+        out = m(**batch, output_attentions=True)
+    assert len(out.attentions) == cfg.num_hidden_layers
+    npz("G5c_tiny_attentions", seed=np.array([5]), batch_seed=np.array([55]), logits=out.logits,
+        attentions=torch.stack(out.attentions, 0))
 
 
 def g6_xlarge(deberta):
@@ -769,8 +843,10 @@ def main():
         "G1": lambda: g1_adapter(adapter_mod),
         "G2": lambda: g2_relpos(deberta),
         "G3": lambda: g3_attention(deberta),
+        "G3b": lambda: g3b_attention_backward(deberta),
         "G4": lambda: g4_layer_conv(deberta),
         "G5": lambda: g5_tiny_model(deberta),
+        "G5c": lambda: g5c_attentions(deberta),
         "G6": lambda: g6_xlarge(deberta),
         "G7": lambda: g7_misc(misc),
         "G8": g8_bert,

@@ -101,6 +101,66 @@ def test_g3_attention_stage(golden, S):
         assert (got[0, S - 5:] == 0).all()  # padded query rows: XSoftmax gives exact zeros
 
 
+@pytest.mark.parametrize("S", [37, 266])
+def test_g3b_attention_backward_stage(golden, S):
+    """The attention backward kernels (prep, dS / dV, the two shear passes, the position-table products) on the reference
+    module's inputs and a seeded upstream gradient, against the gradients the REFERENCE's own backward left on the outputs of
+    query_proj / key_proj / value_proj -- token rows: dq, dk, dv; relative-position rows: dPQ, dPK (G3b; hooks on the
+    reference module, tests/golden/make_goldens.py).  Until round 4 this stage was only checked against the builder's own
+    restatement (tests/gpu_refs.py) and, in aggregate, through the model-level gradient goldens."""
+    import types
+
+    from frozenbilm_amd import lib as L
+    from frozenbilm_amd.attn_bwd import disent_attn_bwd
+
+    g, gb = golden("G3_attention"), golden("G3b_attention_backward")
+    cfg = _tiny_cfg()
+    m = build(cfg, O.synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1))
+    hidden, qs, mask, dy = g[f"hidden_{S}"], g[f"qs_{S}"], g[f"mask_{S}"], gb[f"dy_{S}"]
+    eng, run, r = _engine_run(m, mask)
+    B, H, nh, N, P_ = run.B, eng.H, eng.nh, run.B * S, eng.span2
+    Sp = (S + 63) // 64 * 64
+    W = eng.Lw[1]
+    sl = (lambda t: t) if S == 37 else (lambda t: t[:, ::3])
+    for tag, q_in in (("", None), ("q", qs)):
+        kv = _stream(eng, hidden)
+        kv.full[N:].copy_(r.bf16)
+        qkv = torch.empty(N + P_, 3 * H, dtype=BF16, device=DEV)
+        if q_in is None:
+            L.gemm(kv.full, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
+        else:
+            q = _stream(eng, q_in)
+            q.full[N:].copy_(r.bf16)
+            L.gemm(q.full, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
+            L.gemm(kv.full, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
+        ctx = torch.empty(N, H, dtype=BF16, device=DEV)
+        lse = torch.empty(B, nh, S, dtype=F32, device=DEV)
+        L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], qkv[:N, 2 * H:], qkv[N:, H:2 * H], qkv[N:, :H], eng.relidx(S),
+                          run.mask_i32, 1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, P_, klen=run.klen, border=run.border,
+                          lin=eng.lin_span)
+        sv = types.SimpleNamespace(qkv=qkv[:N], pqk=qkv[N:, : 2 * H], ctx=ctx, lse=lse, seed_att=0)
+        dctx = dy.reshape(N, H).to(DEV).to(BF16).contiguous()
+        dqkv = torch.full((N, 3 * H), float("nan"), dtype=BF16, device=DEV)
+        dpqk = torch.empty(P_, 2 * H, dtype=BF16, device=DEV)
+        disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk)
+        torch.cuda.synchronize()
+        got = dqkv.float().cpu().view(B, S, 3 * H)
+        worst = {}
+        for name, lo in (("dq", 0), ("dk", H), ("dv", 2 * H)):
+            ref = gb[f"{name}{tag}_{S}"].float()
+            out = sl(got[:, :, lo:lo + H])
+            worst[name] = (out - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        for name, lo in (("dpq", 0), ("dpk", H)):
+            ref = gb[f"{name}{tag}_{S}"].float()
+            out = dpqk[:, lo:lo + H].float().cpu()
+            worst[name] = (out - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        print(f"G3b S={S} query_states={'yes' if tag else 'no'}: max-abs error / max |reference| per gradient: "
+              + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+        # bf16 operands (q, k, v, dO, P, dS all rounded to bf16 on the way) against the fp32 reference
+        assert all(v < 3e-2 for v in worst.values()), worst
+        assert torch.isfinite(got).all()  # every row of dq / dk / dv written (padded rows included)
+
+
 def test_g4_layer_and_conv_stages(golden):
     """the engine's layer stage (attention + adapters + FFN + LayerNorms; encoder form and EMD form with query_states)
     and conv stage on the reference DebertaV2Layer / ConvLayer inputs"""

@@ -58,6 +58,40 @@ def test_tiny_forward_golden(golden):
     assert out["loss"] is out.loss  # item + attribute access like MaskedLMOutput
 
 
+def test_output_attentions_golden(golden):
+    """output_attentions=True (model/deberta.py:1414-1427): one [B, heads, S, S] probability tensor per encoder layer, equal
+    to the reference's `attentions` tuple (G5c); masked pairs and masked query rows exactly 0; the other outputs of the
+    call are those of the plain forward; a training-mode request (attention dropout live) is refused."""
+    g5, gc = golden("G5_tiny_model"), golden("G5c_tiny_attentions")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P)
+    batch = to_dev({k[3:]: v for k, v in g5.items() if k.startswith("in.")})
+    with torch.no_grad():
+        out = m(**batch, output_attentions=True)
+        plain = m(**batch)
+    assert plain.attentions is None and torch.equal(out.logits, plain.logits)
+    att = out.attentions
+    ref = gc["attentions"]
+    assert isinstance(att, tuple) and len(att) == cfg.num_hidden_layers == ref.shape[0]
+    worst = 0.0
+    for li, a in enumerate(att):
+        assert a.shape == ref[li].shape and a.dtype == torch.float32
+        worst = max(worst, (a.cpu() - ref[li]).abs().max().item())
+        assert (a.cpu()[ref[li] == 0] == 0).all(), "masked pairs / masked query rows must be exactly 0"
+        rows = a.sum(-1).cpu()
+        live = ref[li].sum(-1) > 0.5
+        assert (rows[live] - 1).abs().max().item() < 2e-2
+    print(f"attention probabilities vs reference: max-abs err {worst:.2e}")
+    assert worst < 2e-2, worst
+    assert (out.logits.float().cpu() - g5["logits"]).abs().max().item() < 5e-2
+    tup = m(**batch, output_attentions=True, return_dict=False)
+    assert isinstance(tup[-1], tuple) and len(tup[-1]) == cfg.num_hidden_layers
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(**batch, output_attentions=True)
+
+
 def test_tiny_text_only_golden(golden):
     g5, gb = golden("G5_tiny_model"), golden("G5b_tiny_textonly")
     cfg = _tiny_cfg()

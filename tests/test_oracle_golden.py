@@ -62,6 +62,50 @@ def test_g3_attention(golden, S):
     assert (y0[0, S - 5:] == 0).all()
 
 
+@pytest.mark.parametrize("S", [37, 266])
+def test_g3b_attention_backward(golden, S):
+    """autograd of the oracle's attention against the reference's own backward of DisentangledSelfAttention (G3b): input
+    gradients w.r.t. hidden_states, query_states and the (LayerNorm-ed) relative-position table, for a seeded upstream dy"""
+    g, gb = golden("G3_attention"), golden("G3b_attention_backward")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=3, std=0.05, ln_jitter=0.1)
+    hidden, qs, mask, dy = g[f"hidden_{S}"], g[f"qs_{S}"], g[f"mask_{S}"], gb[f"dy_{S}"]
+    m = mask.float()
+    mask4d = (m[:, None, None, :] * m[:, None, :, None]).to(torch.uint8)
+    rel = O.relative_position(S, S, 256, 512)
+    pre = "deberta.encoder.layer.1.attention.self"
+    sl = (lambda t: t) if S == 37 else (lambda t: t[:, ::3])
+    tol = 2e-5 if S == 37 else 2e-3  # S=266 is stored in fp16
+    for tag, use_q in (("", False), ("q", True)):
+        h = hidden.clone().requires_grad_(True)
+        q = qs.clone().requires_grad_(True) if use_q else None
+        remb = g["rel_emb"].clone().requires_grad_(True)
+        y = O.disentangled_attention(h, mask4d, rel, remb, P, pre, cfg, query_states=q)
+        y.backward(dy)
+        scale = lambda ref: max(1.0, ref.abs().max().item())
+        for got, key in ((sl(h.grad), f"dhidden{tag}_{S}"), (remb.grad, f"drel{tag}_{S}")) + (((sl(q.grad), f"dqs_{S}"),) if use_q else ()):
+            ref = gb[key].float()
+            assert maxabs(got, ref) < tol * scale(ref), (key, maxabs(got, ref))
+
+
+def test_g5c_attention_probabilities(golden):
+    """the oracle's attention probabilities per encoder layer against the reference's `attentions` tuple (G5c), on the
+    hidden states the reference itself produced for the same forward (G5)"""
+    g5, gc = golden("G5_tiny_model"), golden("G5c_tiny_attentions")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    mask = torch.cat([g5["in.video_mask"], g5["in.attention_mask"]], 1).float()
+    S = mask.shape[1]
+    mask4d = (mask[:, None, None, :] * mask[:, None, :, None]).to(torch.uint8)
+    rel = O.relative_position(S, S, 256, 512)
+    remb = O._ln(P["deberta.encoder.rel_embeddings.weight"], P, "deberta.encoder.LayerNorm", cfg.layer_norm_eps)
+    assert gc["attentions"].shape[0] == cfg.num_hidden_layers
+    for li in range(cfg.num_hidden_layers):
+        _, probs = O.disentangled_attention(g5["hidden_states"][li], mask4d, rel, remb, P,
+                                            f"deberta.encoder.layer.{li}.attention.self", cfg, return_probs=True)
+        assert maxabs(probs, gc["attentions"][li]) < 2e-5, li
+
+
 def test_g4_layer_conv(golden):
     g = golden("G4_layer_conv")
     cfg = _tiny_cfg()
