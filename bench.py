@@ -250,6 +250,19 @@ def main():
         batch.clear(); batch.update(keep)
         extras["host"] = {"enqueue_ms_per_step": d * 1e3, "note": "wall time per step of the same launch sequence at B=1 "
                           "(GPU work per launch negligible): upper bound of the host cost of a step"}
+        # the same step with model.training_graphs (forward and backward replayed as two hipGraphs; clip + Adam eager): GPU
+        # time per step, and the host cost where the GPU cannot hide it (B=1, as `host` above)
+        model.training_graphs = True
+        d = timed(lambda: step(False), n_x)
+        batch.clear(); batch.update(small)
+        dh = timed(lambda: step(False), n_x)
+        batch.clear(); batch.update(keep)
+        model.training_graphs = False
+        model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
+        extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                  "enqueue_ms_per_step": dh * 1e3,
+                                  "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
+                                          "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step = wall time per step at B=1"}
         if world == 1 and full_cfg:
             # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
             # and with the opt-in one-step-delayed loss check

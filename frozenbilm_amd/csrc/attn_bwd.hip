@@ -150,7 +150,7 @@ struct BwdAArgs {
   const bf16* pk; const bf16* pq; long ldp;
   const int16_t* relidx; const int32_t* mask; const int32_t* klen; const int32_t* border;
   const float* lse; const float* Dv;                      // [B,nh,S]
-  float scale, p_drop; uint64_t seed;
+  float scale, p_drop; uint64_t seed; const uint64_t* seed_dev;
   bf16* dV; long lddv;                                    // row-major out, head h at col h*64
   bf16* dS; bf16* dST;                                    // [B,nh,Sp,Sp]
   int B, S, Sp, nh, span2;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   f32x4 dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
+  const DropKey dk = attn_drop_key(a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0, b * a.nh + h, a.p_drop);
   const float k2 = a.scale * LOG2E;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
   const int izero = a.relidx[S - 1];  // idx(0)
@@ -662,13 +662,13 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
                                       int64_t ldo,
                                       const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                                       const int32_t* mask, const int32_t* klen, const int32_t* border, const float* lse, const float* Dv, float scale, float p_drop,
-                                      uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
+                                      uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
                                       int nh, int span2, int lin_span, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
-  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
+  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, seed_dev, (bf16*)dV, lddv,
              (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span};
   attn_debug_init();
   const int smem_bytes = a_total(Sp);

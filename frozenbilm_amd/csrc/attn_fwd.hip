@@ -30,7 +30,7 @@ struct AttnArgs {
   const int32_t* klen;  // [B] last valid position + 1 (tiles beyond it are exactly zero and skipped) or null
   const int32_t* border;  // [B] order in which the samples are dispatched (longest first) or null
   float scale, p_drop;
-  uint64_t seed;
+  uint64_t seed; const uint64_t* seed_dev;
   bf16* ctx;
   long ldo;
   float* lse;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const DropKey dk = attn_drop_key(a.seed, b * a.nh + h, a.p_drop);
+  const DropKey dk = attn_drop_key(a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0, b * a.nh + h, a.p_drop);
   const float k2 = a.scale * LOG2E;  // scores stay unscaled; softmax runs in the exp2 domain
   const int tq = Sp - 1;             // idx[i - j + tq]
   const int izero = a.relidx[S - 1];  // idx(0)
@@ -396,13 +396,13 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
                                    const void* pk, const void* pq, int64_t ldp,
                                    const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                                    const int32_t* border, float scale, float p_drop, uint64_t seed,
-                                   void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
+                                   const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
                                    int lin_span, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldp % 8) || (ldo % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;  // idx(0) +- (lin_span - 1 + 79) must stay inside the table
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, seed_dev, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0};
   static const int dbg = FBL_ENV_INT("FBL_ATTN_DBG", 0);
   a.dbg = dbg;
   attn_debug_init();

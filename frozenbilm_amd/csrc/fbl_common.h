@@ -84,6 +84,12 @@ __device__ __forceinline__ uint32_t fbl_hash(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ float fbl_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
   return (fbl_hash(seed, idx) >= thresh) ? inv_keep : 0.0f;
 }
+// Effective seed of a dropout site: the launch-time value plus an optional device-resident 64-bit word.  With the word a
+// captured launch (hipGraph replay) draws a new mask every time the host advances it -- the seed itself is a kernel argument
+// and frozen into the graph.  NULL: the launch-time value alone.
+__device__ __forceinline__ uint64_t fbl_seed(uint64_t seed, const uint64_t* seed_dev) {
+  return seed_dev ? seed + *seed_dev : seed;
+}
 // host+device: p -> 32-bit threshold (drop iff hash < thresh)
 static inline __host__ __device__ uint32_t fbl_drop_thresh(float p) {
   double t = (double)p * 4294967296.0;

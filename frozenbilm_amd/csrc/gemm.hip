@@ -424,7 +424,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
                         float p_drop, uint64_t drop_seed, void* stream, int seg_n = 0, void* seg_out = nullptr,
                         int64_t seg_ld = 0, int64_t drop_row0 = 0, void* aux_stream = nullptr,
-                        const TailArgs* tail = nullptr) {
+                        const TailArgs* tail = nullptr, const uint64_t* drop_seed_dev = nullptr) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if ((aux_kind == FBL_AUX_ADAPTER_TAIL) != (tail != nullptr)) return FBL_ERR_ARG;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
@@ -455,7 +455,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.a_kblk = a_kblock_stride;
   g.kskip_len = kskip_len;
   g.kskip_steps = kskip_steps;
-  g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
+  g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_seed_dev = drop_seed_dev; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
   g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
   g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
   g.r_t = nullptr; g.ld_r = 0; g.r_stats = nullptr; g.r_gamma = nullptr; g.r_beta = nullptr; g.r_rowmask = nullptr;
@@ -550,12 +550,13 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                               out_bf16 ? (char*)out_bf16 + (size_t)m_big * ldc * 2 : nullptr,
                               out_pre_bf16 ? (char*)out_pre_bf16 + (size_t)m_big * ldc * 2 : nullptr, ldc, 1, 0, 0, 0, 0, 0,
                               1, nullptr, (rem_mode & 2) ? -3 : -2, a_kblock_stride, nullptr, 0, p_drop, drop_seed, s_rem, seg_n,
-                              seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big);
+                              seg_out ? (char*)seg_out + (size_t)m_big * seg_ld * 2 : nullptr, seg_ld, drop_row0 + m_big, nullptr,
+                              nullptr, drop_seed_dev);
         if (rc) return rc;
         if (forked && hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess) return FBL_ERR_ARG;
         rc = gemm_nt_impl(A, lda, B, ldb, m_big, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32,
                           out_bf16, out_pre_bf16, ldc, 1, 0, 0, 0, 0, 0, 1, nullptr, -1, a_kblock_stride, nullptr, 0,
-                          p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0);
+                          p_drop, drop_seed, stream, seg_n, seg_out, seg_ld, drop_row0, nullptr, nullptr, drop_seed_dev);
         if (rc) return rc;
         if (forked && hipStreamWaitEvent((hipStream_t)stream, ev_join, 0) != hipSuccess) return FBL_ERR_ARG;
         return 0;
@@ -723,10 +724,11 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
 // z[M, A] = dropout(relu(x[M,K] . Wd[A,K]^T + bd)): the adapter's down-projection with ReLU AND dropout in the GEMM
 // epilogue (one launch instead of GEMM + fbl_dropout_bf16).  Element (m, a) is keyed by (seed, m*ldz + a).
 extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, int64_t ldw, int M, int A, int K,
-                                    const float* bias, float p_drop, uint64_t seed, void* z_bf16, int64_t ldz,
-                                    void* stream) {
+                                    const float* bias, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* z_bf16,
+                                    int64_t ldz, void* stream) {
   return gemm_nt_impl(x_bf16, ldx, wd_bf16, ldw, M, A, K, bias, nullptr, 1.0f, FBL_ACT_RELU, FBL_AUX_NONE, nullptr, 0,
-                      nullptr, z_bf16, nullptr, ldz, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream);
+                      nullptr, z_bf16, nullptr, ldz, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, 0,
+                      nullptr, 0, 0, nullptr, nullptr, seed_dev);
 }
 
 // One GEMM for a dense layer AND the down-projection of the adapter that follows it (model/deberta.py:255-257, 329-331:
@@ -738,17 +740,17 @@ extern "C" int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void*
 // must not straddle the segment boundary); the 256-wide tiles additionally need N1 % 256 == 0 and are not used otherwise.
 extern "C" int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1,
                                           int A, int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy,
-                                          float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream,
-                                          void* aux_stream) {
+                                          float p_drop, uint64_t seed, const uint64_t* seed_dev, void* z_bf16, int64_t ldz,
+                                          void* stream, void* aux_stream) {
   if (A <= 0 || (N1 & 63)) return FBL_ERR_ARG;
   return gemm_nt_impl(x_bf16, ldx, wm_bf16, ldw, M, N1 + A, K, bias_m, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_NONE, nullptr, 0,
                       y_f32, y_bf16, nullptr, ldy, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, N1,
-                      z_bf16, ldz, 0, aux_stream);
+                      z_bf16, ldz, 0, aux_stream, nullptr, seed_dev);
 }
 
 extern "C" int fbl_adapter_up_resid_fwd(const void* z_bf16, int64_t ldz, const void* wu_bf16, int64_t ldw, int M, int H, int A,
                                         const float* bias_u, const void* x_bf16, int64_t ldx, float p_drop, uint64_t seed,
-                                        const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
+                                        const uint64_t* seed_dev, const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
                                         const float* r_beta, const int32_t* r_rowmask, float* out_t, int64_t ldt,
                                         void* stream) {
   if (!z_bf16 || !wu_bf16 || !x_bf16 || !r_t || !out_t) return FBL_ERR_ARG;
@@ -757,7 +759,7 @@ extern "C" int fbl_adapter_up_resid_fwd(const void* z_bf16, int64_t ldz, const v
   const TailArgs tail{r_t, ld_r, r_stats, r_gamma, r_beta, r_rowmask};
   return gemm_nt_impl(z_bf16, ldz, wu_bf16, ldw, M, H, A, bias_u, nullptr, 1.0f, FBL_ACT_NONE, FBL_AUX_ADAPTER_TAIL, x_bf16, ldx,
                       out_t, nullptr, nullptr, ldt, 1, 0, 0, 0, 0, 0, 1, nullptr, 0, 0, nullptr, 0, p_drop, seed, stream, 0,
-                      nullptr, 0, 0, nullptr, &tail);
+                      nullptr, 0, 0, nullptr, &tail, seed_dev);
 }
 
 extern "C" int fbl_gemm_bf16_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

@@ -37,6 +37,7 @@ struct GemmArgs {
   // post-activation dropout of the epilogue (adapter bottleneck, model/adapter.py:39-41): element (m, n) is keyed by
   // (drop_seed, m*drop_ld + n) exactly like fbl_dropout_bf16 on the [M, drop_ld] output; drop_thresh == 0 -> off
   uint64_t drop_seed;
+  const uint64_t* drop_seed_dev;  // optional device word added to drop_seed (fbl_seed)
   uint32_t drop_thresh;
   float drop_inv_keep;
   long drop_ld;
@@ -111,6 +112,7 @@ __device__ __forceinline__ void gemm_epilogue_seg(const GemmArgs& g, char* smem,
   }
   const int nz = n4 - g.seg_n;
   const bool vec = (n4 + 3 < g.N) && ((g.seg_ld & 3) == 0);
+  const uint64_t dseed = g.drop_thresh ? fbl_seed(g.drop_seed, g.drop_seed_dev) : 0;
 #pragma unroll
   for (int half = 0; half < (MI + 3) / 4; ++half) {
     const int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;
@@ -135,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue_seg(const GemmArgs& g, char* smem,
         for (int r = 0; r < 4; ++r) {
           v[r] = fmaxf(a4[r] * g.alpha + bv[r], 0.f);
           if (g.drop_thresh)
-            v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.seg_ld + (uint64_t)(nz + r), g.drop_thresh, g.drop_inv_keep);
+            v[r] *= fbl_dropout_scale(dseed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.seg_ld + (uint64_t)(nz + r), g.drop_thresh, g.drop_inv_keep);
         }
         bf16* zp = g.seg_out + (long)m * g.seg_ld + nz;
         if (vec) {
@@ -168,6 +170,7 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmArgs& g, char* smem
     bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
   }
   const bool normed = g.r_stats != nullptr;
+  const uint64_t dseed = g.drop_thresh ? fbl_seed(g.drop_seed, g.drop_seed_dev) : 0;
   if (normed) {
     const f32x4 t = *(const f32x4*)(g.r_gamma + nc), u = *(const f32x4*)(g.r_beta + nc);
     gg[0] = t[0]; gg[1] = t[1]; gg[2] = t[2]; gg[3] = t[3];
@@ -224,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmArgs& g, char* smem
         for (int r = 0; r < 4; ++r) {
           v[r] = a4[r] * g.alpha + bv[r] + bf2f(xa[it][r]);
           if (g.drop_thresh)
-            v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
+            v[r] *= fbl_dropout_scale(dseed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
           v[r] += normed ? ((ra[it][r] - st[0]) * st[1] * gg[r] + bb[r]) * st[2] : ra[it][r];
         }
         *(f32x4*)(g.out_f32 + er_c + (long)(it * 4) * g.ldc) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -264,6 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
     for (int r = 0; r < 4; ++r) bv[r] = (n4 + r < g.N) ? bias[n4 + r] : 0.f;
   }
   const bool full = (n4 + 3 < g.N);
+  const uint64_t dseed = (ACT == FBL_ACT_RELU && g.drop_thresh) ? fbl_seed(g.drop_seed, g.drop_seed_dev) : 0;
   // every lane of the wave stores whole 4-column vectors (wave-uniform): together with "all rows of the slab exist" this
   // selects the branch-free copy of the row loop below
   const bool wave_full = vec_ok && __builtin_amdgcn_ballot_w64(full) == ~0ull;
@@ -363,7 +367,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       if (ACT == FBL_ACT_RELU && g.drop_thresh) {  // dropout(relu(.)) of the adapter bottleneck, same keys as fbl_dropout_bf16
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          v[r] *= fbl_dropout_scale(g.drop_seed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
+          v[r] *= fbl_dropout_scale(dseed, (uint64_t)(m + g.drop_row0) * (uint64_t)g.drop_ld + (uint64_t)(n4 + r), g.drop_thresh, g.drop_inv_keep);
       }
       if (AUX != FBL_AUX_NONE) {
         const long ao = er_x + (long)(it * 4) * g.ld_aux;

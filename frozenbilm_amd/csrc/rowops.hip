@@ -42,7 +42,7 @@ __device__ __forceinline__ void stb(bf16* p, const float* v) {
 }
 
 struct LnFwdArgs {
-  const float* y; long ldy; float p_drop; uint64_t seed;
+  const float* y; long ldy; float p_drop; uint64_t seed; const uint64_t* seed_dev;
   const float* r_plain; const float* r_t; const float* r_stats; const float* r_gamma; const float* r_beta;
   const int32_t* r_rowmask;
   const float* gamma; const float* beta; float eps; const int32_t* rowmask;
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   float v[EPL];
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const uint64_t seed = a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0;
   float rmean = 0.f, rrstd = 0.f, rmask = 1.f;
   if (a.r_t) {
     rmean = a.r_stats[2 * (long)row];
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
       ldf<VEC>(a.y + (long)row * a.ldy + col, vv);
       if (a.p_drop > 0.f) {
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) vv[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+        for (int c = 0; c < VEC; ++c) vv[c] *= fbl_dropout_scale(seed, (uint64_t)row * H + col + c, thr, inv_keep);
       }
     } else {
 #pragma unroll
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void ln_mat_kernel(LnMatArgs a) {
 constexpr int LNB_BLOCKS = 768;  // three 4-wave blocks per CU (the kernels run 3 waves per SIMD)
 struct LnBwdArgs {
   const float* dout; const int32_t* rowmask; const float* t; const float* stats; const float* gamma;
-  float p_drop; uint64_t seed; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
+  float p_drop; uint64_t seed; const uint64_t* seed_dev; float* out_dt; bf16* out_dy_bf16; float* out_dy_f32; float* ws; int N, H;
   long ld_dyb;  // row stride of out_dy_bf16 (elements)
 };
 template <int EPL>
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   for (int it = 0; it < NIT; ++it) ldf<VEC>(a.gamma + (it * 64 + lane) * VEC, gam + it * VEC);
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const uint64_t seed = a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0;
   for (int row = blockIdx.x * 4 + wave; row < a.N; row += gridDim.x * 4) {
     const float mean = a.stats[2 * (long)row], rstd = a.stats[2 * (long)row + 1];
     const float om = a.rowmask ? (float)a.rowmask[row] : 1.0f;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         const int e = it * VEC + c;
         dt[c] = rstd * (g[e] - s1 - xh[e] * s2);
         dy[c] = dt[c];
-        if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+        if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(seed, (uint64_t)row * H + col + c, thr, inv_keep);
         dys[e] += dy[c];
       }
       if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(256, 3) void ln_bwd2_kernel(LnBwdArgs a) {
   for (int it = 0; it < NIT; ++it) ldf<VEC>(a.gamma + c0 + (it * 64 + lane) * VEC, gam + it * VEC);
   const uint32_t thr = fbl_drop_thresh(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const uint64_t seed = a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0;
   int par = 0;
   for (int base = blockIdx.x * 2; base < a.N; base += gridDim.x * 2, par ^= 1) {
     const int row = base + slot;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256, 3) void ln_bwd2_kernel(LnBwdArgs a) {
           const int e = it * VEC + c;
           dt[c] = rstd * (g[e] - s1 - xh[e] * s2);
           dy[c] = dt[c];
-          if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(a.seed, (uint64_t)row * H + col + c, thr, inv_keep);
+          if (a.p_drop > 0.f) dy[c] *= fbl_dropout_scale(seed, (uint64_t)row * H + col + c, thr, inv_keep);
           dys[e] += dy[c];
         }
         if (a.out_dt) stf<VEC>(a.out_dt + (long)row * H + col, dt);
@@ -472,7 +475,8 @@ __global__ void col2im3_kernel(const float* dcol, float* dx, int B, int S, int H
   }
 }
 
-__global__ void dropout_gelu_fwd_kernel(const float* c, float p, uint64_t seed, float* out, long n) {
+__global__ void dropout_gelu_fwd_kernel(const float* c, float p, uint64_t seed0, const uint64_t* seed_dev, float* out, long n) {
+  const uint64_t seed = p > 0.f ? fbl_seed(seed0, seed_dev) : 0;
   const uint32_t thr = fbl_drop_thresh(p);
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -481,8 +485,9 @@ __global__ void dropout_gelu_fwd_kernel(const float* c, float p, uint64_t seed, 
     out[i] = gelu_erf(v);
   }
 }
-__global__ void dropout_gelu_bwd_kernel(const float* dy, const float* c, float p, uint64_t seed, bf16* ob, float* of,
-                                        long n) {
+__global__ void dropout_gelu_bwd_kernel(const float* dy, const float* c, float p, uint64_t seed0, const uint64_t* seed_dev,
+                                        bf16* ob, float* of, long n) {
+  const uint64_t seed = p > 0.f ? fbl_seed(seed0, seed_dev) : 0;
   const uint32_t thr = fbl_drop_thresh(p);
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -651,7 +656,8 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, l
   const int row = rows[r];
   const int lab = (int)labels[row];
   const float lse = row_lse[row];
-  const float sc = gscale * (gscale_dev ? gscale_dev[0] : 1.0f) / fmaxf(loss_sum_cnt[1], 1.0f);
+  // (an ignored row -- label < 0: the padding entries of a fixed-capacity row list -- has exactly zero gradient)
+  const float sc = lab < 0 ? 0.f : gscale * (gscale_dev ? gscale_dev[0] : 1.0f) / fmaxf(loss_sum_cnt[1], 1.0f);
   const float* x = logits + (long)row * ldv;
   bf16* o = out + (long)r * Vp;
   const bool vec = ((ldv & 3) == 0) && ((Vp & 3) == 0) && (((uintptr_t)logits & 15) == 0) && (((uintptr_t)out & 7) == 0);
@@ -660,12 +666,12 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, l
     const f32x4 v = *(const f32x4*)(x + 4 * i);
     float g[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = (__expf(v[e] - lse) - ((4 * i + e) == lab ? 1.f : 0.f)) * sc;
+    for (int e = 0; e < 4; ++e) g[e] = lab < 0 ? 0.f : (__expf(v[e] - lse) - ((4 * i + e) == lab ? 1.f : 0.f)) * sc;
     *(bf16x4*)(o + 4 * i) = (bf16x4){f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
   }
   for (int i = 4 * V4 + threadIdx.x; i < Vp; i += 256) {
     float g = 0.f;
-    if (i < V) g = (__expf(x[i] - lse) - (i == lab ? 1.f : 0.f)) * sc;
+    if (i < V && lab >= 0) g = (__expf(x[i] - lse) - (i == lab ? 1.f : 0.f)) * sc;
     o[i] = f2bf(g);
   }
 }
@@ -713,7 +719,8 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, l
 __global__ void cast_bf16_kernel(const float* in, bf16* out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
 }
-__global__ void dropout_f32_kernel(const float* in, float p, uint64_t seed, float* of, bf16* ob, long n) {
+__global__ void dropout_f32_kernel(const float* in, float p, uint64_t seed0, const uint64_t* seed_dev, float* of, bf16* ob, long n) {
+  const uint64_t seed = p > 0.f ? fbl_seed(seed0, seed_dev) : 0;
   const uint32_t thr = fbl_drop_thresh(p);
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -723,7 +730,8 @@ __global__ void dropout_f32_kernel(const float* in, float p, uint64_t seed, floa
     if (ob) ob[i] = f2bf(v);
   }
 }
-__global__ void dropout_bf16_kernel(bf16* x, float p, uint64_t seed, long n) {
+__global__ void dropout_bf16_kernel(bf16* x, float p, uint64_t seed0, const uint64_t* seed_dev, long n) {
+  const uint64_t seed = fbl_seed(seed0, seed_dev);
   const uint32_t thr = fbl_drop_thresh(p);
   const float ik = 1.f / (1.f - p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -750,7 +758,7 @@ inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
     default: return FBL_ERR_SHAPE;                                                                   \
   }
 
-extern "C" int fbl_abi_version(void) { return 3; }
+extern "C" int fbl_abi_version(void) { return 4; }
 
 extern "C" int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
                                 float* out_t, void* stream) {
@@ -784,7 +792,7 @@ extern "C" int fbl_mask_tokens(int64_t* ids, int64_t* labels, int64_t n, const i
   return 0;
 }
 
-extern "C" int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const float* r_plain,
+extern "C" int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const uint64_t* seed_dev, const float* r_plain,
                           const float* r_t, const float* r_stats, const float* r_gamma, const float* r_beta,
                           const int32_t* r_rowmask, const float* gamma, const float* beta, float eps,
                           const int32_t* rowmask, float* out_t, float* out_stats, void* out_bf16, float* out_f32, int N,
@@ -792,7 +800,7 @@ extern "C" int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t se
   if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
   if (r_t && (!r_stats || !r_gamma || !r_beta)) return FBL_ERR_ARG;
   if (N <= 0) return 0;
-  LnFwdArgs a{y, ldy, p_drop, seed, r_plain, r_t, r_stats, r_gamma, r_beta, r_rowmask, gamma, beta, eps, rowmask,
+  LnFwdArgs a{y, ldy, p_drop, seed, seed_dev, r_plain, r_t, r_stats, r_gamma, r_beta, r_rowmask, gamma, beta, eps, rowmask,
               out_t, out_stats, (bf16*)out_bf16, out_f32, N, H};
   dim3 grid((N + 3) / 4);
   FBL_EPL_DISPATCH(H, ln_fwd_kernel, grid, a, (hipStream_t)stream);
@@ -814,14 +822,14 @@ extern "C" int fbl_ln_materialize(const float* t, const float* stats, const floa
 
 extern "C" int64_t fbl_ln_bwd_ws_floats(int H) { return (int64_t)LNB_BLOCKS * 3 * H; }
 extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats,
-                          const float* gamma, float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16,
+                          const float* gamma, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_dt, void* out_dy_bf16,
                           float* out_dy_f32, float* dgamma, float* dbeta, float* dysum, float* ws, int N, int H,
                           int64_t ld_dy_bf16, void* stream) {
   if (H % 64 || H > 2048) return FBL_ERR_SHAPE;
   if (N <= 0) return 0;
   if (ld_dy_bf16 == 0) ld_dy_bf16 = H;
   if (ld_dy_bf16 < H || (ld_dy_bf16 % 8)) return FBL_ERR_ALIGN;
-  LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H, ld_dy_bf16};
+  LnBwdArgs a{dout, rowmask, t, stats, gamma, p_drop, seed, seed_dev, out_dt, (bf16*)out_dy_bf16, out_dy_f32, ws, N, H, ld_dy_bf16};
   int nblk;
   if ((H / 64) % 2 == 0) {  // two waves per row, two rows per block iteration
     nblk = (N + 1) / 2;
@@ -868,18 +876,18 @@ extern "C" int fbl_col2im3(const float* dcol, float* dx, int B, int S, int H, in
   return 0;
 }
 
-extern "C" int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, float* out_f32, int64_t n,
-                                    void* stream) {
+extern "C" int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32,
+                                    int64_t n, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(dropout_gelu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, c, p_drop, seed,
+  hipLaunchKernelGGL(dropout_gelu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, c, p_drop, seed, seed_dev,
                      out_f32, (long)n);
   FBL_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, void* out_bf16,
-                                    float* out_f32, int64_t n, void* stream) {
+extern "C" int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                                    void* out_bf16, float* out_f32, int64_t n, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(dropout_gelu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, c, p_drop, seed,
+  hipLaunchKernelGGL(dropout_gelu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, c, p_drop, seed, seed_dev,
                      (bf16*)out_bf16, out_f32, (long)n);
   FBL_CHECK_LAUNCH();
   return 0;
@@ -1000,18 +1008,19 @@ extern "C" int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void*
   FBL_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, float* out_f32, void* out_bf16,
-                               int64_t n, void* stream) {
+extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32,
+                               void* out_bf16, int64_t n, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, p_drop, seed, out_f32,
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, p_drop, seed, seed_dev, out_f32,
                      (bf16*)out_bf16, (long)n);
   FBL_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, int64_t n, void* stream) {
+extern "C" int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64_t* seed_dev, int64_t n,
+                                void* stream) {
   if (n <= 0 || p_drop <= 0.f) return 0;
   hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (bf16*)inout_bf16, p_drop,
-                     seed, (long)n);
+                     seed, seed_dev, (long)n);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -84,7 +84,10 @@ class Engine:
         self.skip_dead_layer = True
         self._ln_ws = L.ln_bwd_ws(self.H, dev)
         self._cs_ws = L.colsum_ws(max(self.H, self.I), dev)
-        self.sk_ws = torch.empty(16 << 20, dtype=F32, device=dev)  # 64 MiB split-K partials (main stream)
+        # split-K partials (main stream): 192 MiB, enough for the prediction-head backward of ~2000 labelled rows (15 slices x
+        # rows x H floats) -- with a smaller workspace that GEMM falls back to atomic adds and the step stops being
+        # reproducible bit for bit
+        self.sk_ws = torch.empty(48 << 20, dtype=F32, device=dev)
         # trainable-weight gradients are off the critical path (nothing downstream in backward reads them): they run on a
         # side HIP stream and fill the tails of the big dX GEMMs; own workspaces so they never race with the main stream
         self.side = torch.cuda.Stream(device=dev)  # (stream priorities were measured: no effect on the interference)
@@ -265,6 +268,10 @@ class Engine:
             self.refresh_trainable_operands()
             self._ops_version = ver
 
+    def seed_word_value(self) -> int:
+        """the 64-bit word a training pass adds to its per-site dropout seeds: the model's position in its mask stream"""
+        return (self.m.dropout_seed_base() * 0x9E3779B1) & 0x7FFFFFFFFFFFFFFF
+
     def prepare_inference(self):
         """Everything an inference forward needs from OUTSIDE its launch sequence, done now: the bf16 operand copies /
         composed adapter rows are current (rebuilt in place: a captured graph keeps reading the same buffers) and the
@@ -444,10 +451,16 @@ class Engine:
             rows_labelled = torch.nonzero(full_labels != -100).view(-1)
         if train:
             m.step_seed += 1
-        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=m.dropout_seed_base(),
+        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=0,
                   p_hid=self.cfg.hidden_dropout_prob if train else 0.0,
                   p_att=self.cfg.attention_probs_dropout_prob if train else 0.0,
                   p_ad=m.adapter_dropout if train else 0.0)
+        if train:
+            # Dropout seeds = a per-site constant (Run.next_seed: a function of the site index only, so that a captured
+            # launch sequence stays valid) + this device word, the position of the step in the model's mask stream
+            # (include/fbl.h "Dropout seeds").  One word per Run: a backward pass regenerates the masks of ITS forward, however
+            # many forwards ran in between.
+            run.seed_word = torch.full((1,), self.seed_word_value(), dtype=torch.int64, device=self.dev)
         run.mask = mask.view(-1)
         run.want_attn = bool(want_attn)
         if want_attn and train and run.p_att > 0:
@@ -461,7 +474,8 @@ class Engine:
             if need_grad or full_labels is not None:
                 raise RuntimeError("logit_rows is an inference-time option (no labels, no gradient bookkeeping)")
             run.logit_rows = logit_rows.to(self.dev).to(torch.int32).contiguous().view(-1)
-        logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden or want_attn)
+        with L.seed_word(run.seed_word):
+            logits, loss_t = self._forward(run, input_ids.contiguous(), video, use_ans, want_hidden or want_attn)
         Vout = self.n_ans if use_ans else self.V
         if logit_rows is not None:
             res = {"logits": logits[:, :Vout], "loss": None, "run": run}
@@ -842,8 +856,9 @@ class Engine:
             self.side.wait_stream(main)  # inputs (dyb, z, dz, xin_b) are ready once main reaches this point
             with torch.cuda.stream(self.side):
                 dw_work(self.side_ws, self.side_cs_ws)
-            for t in (dyb, z, dz, xin_b):
-                t.record_stream(self.side)  # keep the allocator from recycling them before the side stream is done
+            if not torch.cuda.is_current_stream_capturing():  # (a capture's private pool recycles nothing behind its back)
+                for t in (dyb, z, dz, xin_b):
+                    t.record_stream(self.side)  # keep the allocator from recycling them before the side stream is done
             run.side_used = True
             if self.reducer is not None:  # what a data-parallel bucket has to wait for: the dW work queued so far
                 run.dw_event = torch.cuda.Event()
@@ -957,8 +972,9 @@ class Engine:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 work(self.side_ws)
-            for k in ("G1T", "G2T", "QT", "KT"):
-                pst[k].record_stream(self.side)
+            if not torch.cuda.is_current_stream_capturing():
+                for k in ("G1T", "G2T", "QT", "KT"):
+                    pst[k].record_stream(self.side)
             run.side_used = True
         else:
             work(self.sk_ws)
@@ -1004,15 +1020,22 @@ class Engine:
         else:
             L.scatter_rows_f32(dqr, rows, dq)  # first contribution: dq is still zero at these rows
 
-    def backward(self, run, gloss: Optional[torch.Tensor], glogits: Optional[torch.Tensor] = None):
+    def backward(self, run, gloss: Optional[torch.Tensor], glogits: Optional[torch.Tensor] = None, attach: bool = True):
         """Explicit backward of _forward; accumulates into the flat gradient buffer (p.grad views).  gloss: gradient
-        of the internal MLM loss (or None); glogits: gradient w.r.t. the returned logits [B,S,Vout] (or None)."""
+        of the internal MLM loss (or None); glogits: gradient w.r.t. the returned logits [B,S,Vout] (or None).
+        attach=False: the caller has already made p.grad the views of the flat buffer (a captured backward must not contain
+        the conditional zero fill of attach_grads)."""
         if not run.save:
             raise RuntimeError("forward was run without gradient bookkeeping")
+        with L.seed_word(getattr(run, "seed_word", None)):
+            return self._backward(run, gloss, glogits, attach)
+
+    def _backward(self, run, gloss, glogits, attach):
         cfg, H, dev = self.cfg, self.H, self.dev
         B, S, T = run.B, run.S, run.T
         N = B * S
-        self.attach_grads()
+        if attach:
+            self.attach_grads()
         reducer = self.reducer
 
         red = _Ready(self, run, reducer) if reducer is not None else None
@@ -1174,6 +1197,7 @@ class Run:
     mask: torch.Tensor = None
     labels: torch.Tensor = None
     hidden_out: tuple = None
+    seed_word: Optional[torch.Tensor] = None  # device word added to every dropout seed of this pass (see Engine.run)
     want_attn: bool = False
     attn_out: list = field(default_factory=list)
     seed_emb: int = 0
@@ -1181,7 +1205,7 @@ class Run:
 
     def next_seed(self) -> int:
         self._site += 1
-        return (self.seed_base * 0x9E3779B1 + self._site * 0x85EBCA77) & 0xFFFFFFFFFFFF
+        return (self.seed_base * 0x9E3779B1 + self._site * 0x85EBCA77) & 0xFFFFFFFFFFFF  # (+ the device word, in the kernel)
 
 
 class _StepFn(torch.autograd.Function):

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
+ABI_VERSION = 4  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -26,23 +26,23 @@ SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
                               _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp, _vp]),
-    "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _l, _vp]),
-    "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp]),
-    "fbl_adapter_up_resid_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _f, _u64, _vp, _l, _vp, _vp, _vp, _vp,
+    "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _vp, _l, _vp, _vp]),
+    "fbl_adapter_up_resid_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _f, _u64, _vp, _vp, _l, _vp, _vp, _vp, _vp,
                                       _vp, _l, _vp]),
     "fbl_gemm_bf16_tn_acc": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp]),
     "fbl_adapter_bwd_dw": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_embed_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
-    "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
+    "fbl_ln_fwd": (_i, [_vp, _l, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                         _vp]),
     "fbl_ln_materialize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "fbl_ln_bwd_ws_floats": (_l, [_i]),
-    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
+    "fbl_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
     "fbl_im2col3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "fbl_col2im3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
-    "fbl_dropout_gelu_bwd": (_i, [_vp, _vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_dropout_gelu_fwd": (_i, [_vp, _f, _u64, _vp, _vp, _l, _vp]),
+    "fbl_dropout_gelu_bwd": (_i, [_vp, _vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
     "fbl_video_stage_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_mask_tokens": (_i, [_vp, _vp, _l, _vp, _i, _f, _l, _l, _u64, _vp]),
     "fbl_transpose_to_bf16": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp]),
@@ -50,13 +50,13 @@ SIGNATURES = {
     "fbl_colsum_ws_floats": (_l, [_i]),
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
-    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _l,
+    "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l,
                                  _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _f, _f, _u64, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+                                    _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
@@ -66,8 +66,8 @@ SIGNATURES = {
     "fbl_sumsq": (_i, [_vp, _l, _vp, _vp]),
     "fbl_adam_flat": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "fbl_cast_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
-    "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _l, _vp]),
-    "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _l, _vp]),
+    "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
+    "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
 }
 
 _LIB = None
@@ -136,6 +136,34 @@ def _aux_stream():
     h = st.cuda_stream
     cur = torch.cuda.current_stream().cuda_stream
     return None if (h == cur or cur in _NO_AUX) else h
+
+
+# The device-resident seed word (include/fbl.h "Dropout seeds"): while a word is set -- by the engine, for the launches of one
+# forward / backward pass -- every seeded launch made through this binding passes it as `seed_dev`; otherwise NULL.
+_SEED_WORD = None
+
+
+class seed_word:
+    """context manager: seeded launches inside it add the 64-bit device word `t` (int64 tensor, 1 element) to their seed"""
+
+    def __init__(self, t: Optional[torch.Tensor]):
+        self.t, self.prev = t, None
+
+    def __enter__(self):
+        global _SEED_WORD
+        if self.t is not None:
+            assert self.t.dtype == torch.int64 and self.t.is_cuda and self.t.numel() >= 1
+        self.prev, _SEED_WORD = _SEED_WORD, self.t
+        return self
+
+    def __exit__(self, *exc):
+        global _SEED_WORD
+        _SEED_WORD = self.prev
+        return False
+
+
+def _seed_dev():
+    return None if _SEED_WORD is None else _SEED_WORD.data_ptr()
 
 
 def _chk(code: int, name: str):
@@ -223,7 +251,7 @@ def adapter_down_fwd(x, wd, bias, z, *, A=None, p_drop=0.0, seed=0):
     M, K = x.shape
     A = wd.shape[0] if A is None else A
     assert wd.shape[1] == K and z.shape[0] >= M and z.shape[1] >= A
-    _chk(load().fbl_adapter_down_fwd(_p(x), ldx, _p(wd), ldw, M, A, K, _p(bias), float(p_drop), int(seed), _p(z), ldz,
+    _chk(load().fbl_adapter_down_fwd(_p(x), ldx, _p(wd), ldw, M, A, K, _p(bias), float(p_drop), int(seed), _seed_dev(), _p(z), ldz,
                                      _stream()), "fbl_adapter_down_fwd")
 
 
@@ -242,7 +270,7 @@ def dense_adapter_down_fwd(x, wm, bias_m, N1, z, *, y_f32=None, y_bf16=None, p_d
             assert ldy is None or ldy == l
             ldy = l
     _chk(load().fbl_dense_adapter_down_fwd(_p(x), ldx, _p(wm), ldw, M, N1, A, K, _p(bias_m), _p(y_f32), _p(y_bf16), ldy or 0,
-                                           float(p_drop), int(seed), _p(z), ldz, _stream(), _aux_stream()),
+                                           float(p_drop), int(seed), _seed_dev(), _p(z), ldz, _stream(), _aux_stream()),
          "fbl_dense_adapter_down_fwd")
 
 
@@ -273,7 +301,7 @@ def adapter_up_resid_fwd(z, wu, bias_u, x, out_t, *, A=None, p_drop=0.0, seed=0,
     ld_r = _rows2d(rt, "residual")
     assert rt.shape[0] >= M and rt.shape[1] >= H
     _chk(load().fbl_adapter_up_resid_fwd(_p(z), ldz, _p(wu), ldw, M, H, int(A), _p(bias_u), _p(x), ldx, float(p_drop),
-                                         int(seed), _p(rt), ld_r, _p(rs), _p(rg), _p(rb), _p(rm), _p(out_t), ldt,
+                                         int(seed), _seed_dev(), _p(rt), ld_r, _p(rs), _p(rg), _p(rb), _p(rm), _p(out_t), ldt,
                                          _stream()), "fbl_adapter_up_resid_fwd")
 
 
@@ -353,7 +381,7 @@ def ln_fwd(*, y=None, p_drop=0.0, seed=0, r_plain=None, r_norm=None, gamma, beta
     for t in (r_plain, rt, out_t, out_bf16, out_f32):
         if t is not None:
             assert t.is_contiguous()
-    _chk(load().fbl_ln_fwd(_p(y), ldy, float(p_drop), int(seed), _p(r_plain), _p(rt), _p(rs), _p(rg), _p(rb), _p(rm),
+    _chk(load().fbl_ln_fwd(_p(y), ldy, float(p_drop), int(seed), _seed_dev(), _p(r_plain), _p(rt), _p(rs), _p(rg), _p(rb), _p(rm),
                            _p(gamma), _p(beta), float(eps), _p(rowmask), _p(out_t), _p(out_stats), _p(out_bf16),
                            _p(out_f32), N, H, _stream()), "fbl_ln_fwd")
 
@@ -373,7 +401,7 @@ def ln_bwd(dout, t, stats, gamma, *, rowmask=None, p_drop=0.0, seed=0, out_dt=No
     N, H = t.shape
     assert dout.is_contiguous() and t.is_contiguous()
     ld_dyb = _rows2d(out_dy_bf16, "out_dy_bf16") if out_dy_bf16 is not None else 0
-    _chk(load().fbl_ln_bwd(_p(dout), _p(rowmask), _p(t), _p(stats), _p(gamma), float(p_drop), int(seed), _p(out_dt),
+    _chk(load().fbl_ln_bwd(_p(dout), _p(rowmask), _p(t), _p(stats), _p(gamma), float(p_drop), int(seed), _seed_dev(), _p(out_dt),
                            _p(out_dy_bf16), _p(out_dy_f32), _p(dgamma), _p(dbeta), _p(dysum), _p(ws), N, H, ld_dyb,
                            _stream()), "fbl_ln_bwd")
 
@@ -387,12 +415,12 @@ def col2im3(dcol, dx, B, S, H, accumulate):
 
 
 def dropout_gelu_fwd(c, p_drop, seed, out_f32):
-    _chk(load().fbl_dropout_gelu_fwd(_p(c), float(p_drop), int(seed), _p(out_f32), c.numel(), _stream()),
+    _chk(load().fbl_dropout_gelu_fwd(_p(c), float(p_drop), int(seed), _seed_dev(), _p(out_f32), c.numel(), _stream()),
          "fbl_dropout_gelu_fwd")
 
 
 def dropout_gelu_bwd(dy, c, p_drop, seed, out_bf16=None, out_f32=None):
-    _chk(load().fbl_dropout_gelu_bwd(_p(dy), _p(c), float(p_drop), int(seed), _p(out_bf16), _p(out_f32), c.numel(),
+    _chk(load().fbl_dropout_gelu_bwd(_p(dy), _p(c), float(p_drop), int(seed), _seed_dev(), _p(out_bf16), _p(out_f32), c.numel(),
                                      _stream()), "fbl_dropout_gelu_bwd")
 
 
@@ -473,7 +501,7 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     ldq, ldk, ldv, ldp, ldo = _rows2d(q, "q"), _rows2d(k, "k"), _rows2d(v, "v"), _rows2d(pk, "pk"), _rows2d(ctx, "ctx")
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
-                                    _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _p(ctx), ldo,
+                                    _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _seed_dev(), _p(ctx), ldo,
                                     _p(lse), B, S, Sp, nh, span2, int(lin), _stream()), "fbl_disent_attn_fwd")
 
 
@@ -512,7 +540,7 @@ def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS
     ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(pk), _p(pq), ldp,
-                                       _p(relidx), _p(mask), _p(klen), _p(border), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed),
+                                       _p(relidx), _p(mask), _p(klen), _p(border), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed), _seed_dev(),
                                        _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, int(lin), _stream()),
          "fbl_disent_attn_bwd_ds")
 
@@ -577,11 +605,11 @@ def cast_bf16(x, out):
 def dropout_f32(x, p_drop, seed, out_f32=None, out_bf16=None):
     _req(x, torch.float32, "x")
     assert x.is_contiguous()
-    _chk(load().fbl_dropout_f32(_p(x), float(p_drop), int(seed), _p(out_f32), _p(out_bf16), x.numel(), _stream()),
+    _chk(load().fbl_dropout_f32(_p(x), float(p_drop), int(seed), _seed_dev(), _p(out_f32), _p(out_bf16), x.numel(), _stream()),
          "fbl_dropout_f32")
 
 
 def dropout_bf16_(x, p_drop, seed):
     _req(x, torch.bfloat16, "x")
     assert x.is_contiguous()
-    _chk(load().fbl_dropout_bf16(_p(x), float(p_drop), int(seed), x.numel(), _stream()), "fbl_dropout_bf16")
+    _chk(load().fbl_dropout_bf16(_p(x), float(p_drop), int(seed), _seed_dev(), x.numel(), _stream()), "fbl_dropout_bf16")

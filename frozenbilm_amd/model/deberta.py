@@ -224,6 +224,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
         self._engine = None
         self.inference_graphs = False  # opt-in: replay the `logit_rows` inference forward as one hipGraph (_graph_forward)
+        self.training_graphs = False  # opt-in: the MLM training step as two replayed hipGraphs (train_graph.py)
         self._weights_frozen = 0  # nesting depth of weights_frozen(): inference forwards may reuse the packed operands
         self._reducer = None  # parallel.GradReducer attached to this model (survives engine rebuilds)
         self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
@@ -311,6 +312,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         """Drop the packed bf16 operands / flat buffers (after load_state_dict, .to(), set_answer_embeddings)."""
         self._engine = None
         self.__dict__.pop("_graph_cache", None)  # captured graphs hold the old engine's buffers
+        self.__dict__.pop("_train_graphs", None)
 
     def _load_from_state_dict(self, *a, **k):
         self.invalidate()
@@ -452,6 +454,20 @@ class DebertaV2ForMaskedLM(nn.Module):
             if logits is not None:
                 out = MaskedLMOutput(loss=None, logits=logits, hidden_states=None, attentions=None)
                 return out if return_dict is not False else (logits,)
+        if (self.training_graphs and self.training and labels is not None and not output_hidden_states and not output_attentions
+                and logit_rows is None and not (self.n_ans and not mlm) and torch.is_grad_enabled()):
+            from ..train_graph import graphed_forward
+
+            got = graphed_forward(self, eng, input_ids, attention_mask, video, video_mask, labels)
+            if got is not None:
+                loss, run = got
+                B, S = run.B, run.S
+                # (the logits of a graphed step carry no autograd edge: gradients flow through `.loss`)
+                out = MaskedLMOutput(loss=loss, logits=run.logits.view(B, S, -1)[:, :, : run.Vout], hidden_states=None,
+                                     attentions=None)
+                out.__dict__["_run"] = run
+                out.__dict__["_fill"] = lambda: eng.fill_logits(run)
+                return out if return_dict is not False else (out["loss"], out["logits"])
         # output_attentions=True (model/deberta.py:1414-1427, :544-560): the fused attention kernel never materialises its
         # probabilities; on request a plain kernel rebuilds them per encoder layer from the stored log-sum-exp (eval mode)
         res = eng.run(input_ids, attention_mask, video, video_mask, labels, mlm, output_hidden_states, logit_rows=logit_rows,

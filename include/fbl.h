@@ -26,6 +26,12 @@ extern "C" {
 #define FBL_ERR_ALIGN (-2)
 #define FBL_ERR_ARG (-3)
 
+/* Dropout seeds.  Every entry point with a dropout site takes `uint64_t seed` and, right behind it, `const uint64_t*
+ * seed_dev` (device pointer or NULL): the mask of element e is a pure function of (seed + *seed_dev, e) -- seed alone when
+ * seed_dev is NULL -- so a backward launch given the same pair regenerates the forward's mask.  The device word exists for
+ * launch graphs: `seed` is a kernel argument and frozen into a captured launch, the word is read when the kernel runs, so
+ * advancing it between replays gives every replay fresh masks. */
+
 enum {
   FBL_ACT_NONE = 0,
   FBL_ACT_GELU = 1,
@@ -42,7 +48,7 @@ enum {
   FBL_AUX_ADAPTER_TAIL = 6    /* internal to fbl_adapter_up_resid_fwd; fbl_gemm_bf16_nt rejects it                */
 };
 
-/* Bumped whenever an exported argument list changes (3: this header); the ctypes binding refuses any other value. */
+/* Bumped whenever an exported argument list changes (4: this header); the ctypes binding refuses any other value. */
 int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
@@ -79,7 +85,8 @@ int fbl_gemm_plan(int M, int N, int K, int batch, int splitk);
  * The backward needs no mask: d/dz passes where z > 0, scaled by 1/(1-p) (FBL_AUX_MUL_POS_BF16 with alpha).
  * ref: model/adapter.py:38-41 (down -> ReLU -> nn.Dropout). */
 int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, int64_t ldw, int M, int A, int K,
-                         const float* bias, float p_drop, uint64_t seed, void* z_bf16, int64_t ldz, void* stream);
+                         const float* bias, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* z_bf16, int64_t ldz,
+                         void* stream);
 
 /* A dense layer and the down-projection of the adapter behind it as ONE GEMM.  wm = [W ; Wd.W] ([N1 + A, K] bf16: the
  * lower A rows hold the adapter's down-projection composed with the dense weight -- the caller rebuilds them, with
@@ -91,7 +98,8 @@ int fbl_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wd_bf16, i
  * ref: model/deberta.py:255-257, 329-331 (dense -> adapter) + model/adapter.py:38-41. */
 int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_bf16, int64_t ldw, int M, int N1, int A,
                                int K, const float* bias_m, float* y_f32, void* y_bf16, int64_t ldy, float p_drop,
-                               uint64_t seed, void* z_bf16, int64_t ldz, void* stream, void* aux_stream);
+                               uint64_t seed, const uint64_t* seed_dev, void* z_bf16, int64_t ldz, void* stream,
+                               void* aux_stream);
 
 /* Everything between an adapter's bottleneck and the LayerNorm statistics behind it, as the epilogue of the up-projection:
  *   t[M, H] = dropout_p( x[M,H] + z[M,A] . Wu[H,A]^T + bu ) + resid[M,H]                      (fp32 out, row stride ldt)
@@ -104,7 +112,7 @@ int fbl_dense_adapter_down_fwd(const void* x_bf16, int64_t ldx, const void* wm_b
  * ref: model/adapter.py:42-45 (up + residual), model/deberta.py:258-259, 332-333 (dropout; LayerNorm(. + input_tensor)). */
 int fbl_adapter_up_resid_fwd(const void* z_bf16, int64_t ldz, const void* wu_bf16, int64_t ldw, int M, int H, int A,
                              const float* bias_u, const void* x_bf16, int64_t ldx, float p_drop, uint64_t seed,
-                             const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
+                             const uint64_t* seed_dev, const float* r_t, int64_t ld_r, const float* r_stats, const float* r_gamma,
                              const float* r_beta, const int32_t* r_rowmask, float* out_t, int64_t ldt, void* stream);
 
 /* Weight and bias gradients of a GROUP of bottleneck adapters of one shape, accumulated (+=) by ONE launch:
@@ -161,7 +169,7 @@ int fbl_mask_tokens(int64_t* ids, int64_t* labels, int64_t n, const int64_t* spe
  *  writes out_t fp32 [N,H] (pre-LN, saved for backward), out_stats fp32 [N,2], out_bf16 [N,H] (GEMM operand),
  *  out_f32 optional.  H % 64 == 0, H <= 2048.
  * ref: model/deberta.py:258-259, 332-333 (dropout + residual + LayerNorm), :1043-1054 (embeddings), :405-417 (conv). */
-int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const float* r_plain, const float* r_t,
+int fbl_ln_fwd(const float* y, int64_t ldy, float p_drop, uint64_t seed, const uint64_t* seed_dev, const float* r_plain, const float* r_t,
                const float* r_stats, const float* r_gamma, const float* r_beta, const int32_t* r_rowmask,
                const float* gamma, const float* beta, float eps, const int32_t* rowmask, float* out_t,
                float* out_stats, void* out_bf16, float* out_f32, int N, int H, void* stream);
@@ -181,7 +189,7 @@ int fbl_ln_materialize(const float* t, const float* stats, const float* gamma, c
  * ref: autograd of torch.nn.LayerNorm + XDropout.backward (model/deberta.py:185-190). */
 int64_t fbl_ln_bwd_ws_floats(int H);
 int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float* t, const float* stats, const float* gamma,
-               float p_drop, uint64_t seed, float* out_dt, void* out_dy_bf16, float* out_dy_f32, float* dgamma,
+               float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_dt, void* out_dy_bf16, float* out_dy_f32, float* dgamma,
                float* dbeta, float* dysum, float* ws, int N, int H, int64_t ld_dy_bf16, void* stream);
 
 /* out[n, k*H + c] = x[b, s+k-1, c] (0 outside the sequence), n = b*S+s, k in {0,1,2}: im2col for the 3-tap conv.
@@ -191,9 +199,10 @@ int fbl_im2col3(const void* x_bf16, void* out_bf16, int B, int S, int H, void* s
 int fbl_col2im3(const float* dcol, float* dx, int B, int S, int H, int accumulate, void* stream);
 
 /* y = gelu(dropout(c)) elementwise, fp32 -> fp32 (+ optional bf16).  ref: model/deberta.py:403. */
-int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, float* out_f32, int64_t n, void* stream);
+int fbl_dropout_gelu_fwd(const float* c, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32, int64_t n,
+                         void* stream);
 /* dc = dy * gelu'(dropout(c)) * dropscale ; writes bf16 (GEMM operand) */
-int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, void* out_bf16, float* out_f32,
+int fbl_dropout_gelu_bwd(const float* dy, const float* c, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* out_bf16, float* out_f32,
                          int64_t n, void* stream);
 
 /* out_bf16[c, r] = in[r, c] for r < rows, 0 for rows <= r < rows_pad; in is fp32 (in_is_bf16=0) or bf16.
@@ -235,7 +244,7 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
 int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                         const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                         const int32_t* mask, const int32_t* klen, const int32_t* border, float scale, float p_drop,
-                        uint64_t seed, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
+                        uint64_t seed, const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
                         int lin_span, void* stream);
 
 /* The attention probabilities of fbl_disent_attn_fwd, materialised on request (output_attentions=True; never on the hot
@@ -273,7 +282,7 @@ int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq,
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                            const int32_t* border, const float* lse, const float* Dv,
-                           float scale, float p_drop, uint64_t seed, void* dV, int64_t lddv, void* dS, void* dST, int B,
+                           float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B,
                            int S, int Sp, int nh, int span2, int lin_span, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
                               const void* PT, const int16_t* relidx, const int32_t* klen, const int32_t* border,
@@ -308,9 +317,9 @@ int fbl_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float
 int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 /* counter-based dropout (element i keyed by seed): fp32 in -> fp32 and/or bf16 out (in-place allowed);
  * bf16 in place.  ref: StableDropout / XDropout model/deberta.py:171-217, nn.Dropout model/adapter.py:41. */
-int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, float* out_f32, void* out_bf16, int64_t n,
+int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32, void* out_bf16, int64_t n,
                     void* stream);
-int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, int64_t n, void* stream);
+int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64_t* seed_dev, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

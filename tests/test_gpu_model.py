@@ -750,7 +750,10 @@ def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path, overlap)
     the attention-backward windows, or once after backward."""
     got = _run_two_ranks(tmp_path, overlap, "tiny")
     assert got["ranks_agree"] and got["world"] == 2 and got["covers"] and got["overlap"] == overlap
-    assert (got["collectives"] >= 3) if overlap != "after" else (got["collectives"] == 1), got["launch_order"]
+    # ("attention_windows" at the tiny size: its six adapters never fill a gradient group, every stage becomes final after
+    #  the last window -- one collective; the xlarge-dimension test below sees windows that carry buckets)
+    want_n = {"backward": lambda n: n >= 3, "after": lambda n: n == 1, "attention_windows": lambda n: n >= 1}[overlap]
+    assert want_n(got["collectives"]), got["launch_order"]
     print(f"backend {got['backend']} (RCCL ranks: {got['rccl_ranks']}), {got['collectives']} bucket collectives per step")
     cfg = _tiny_cfg()
     want, losses = _single_process_reference(cfg, O.synth_params(cfg, seed=41, std=0.05, ln_jitter=0.1), 60)
@@ -845,3 +848,49 @@ def test_delayed_loss_check_gives_the_same_epoch_statistics():
     for k in stats_out[0]:
         assert abs(stats_out[0][k] - stats_out[1][k]) < 1e-6, (k, stats_out)
     assert torch.equal(finals[0], finals[1])
+
+
+def test_graphed_training_step_equals_the_eager_step():
+    """model.training_graphs: forward and backward of the MLM step replayed as two hipGraphs (train_graph.py).  Same kernels,
+    same inputs, same seeds (per-site constants + the device word rewritten before every replay): three optimizer steps on
+    three different batches leave exactly the parameters the eager loop leaves; dropout is live and differs between steps;
+    `.logits` of a graphed step are filled on access; a second forward before backward is refused; an eval forward and a
+    shape change in between do not disturb the captured graphs."""
+    from frozenbilm_amd.optim import FusedAdam
+
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=47, std=0.05, ln_jitter=0.1)
+    batches = [to_dev(synth_batch(cfg, B=4, L=40, seed=60 + i)) for i in range(3)]
+    other = to_dev(synth_batch(cfg, B=2, L=24, seed=70))
+    results = []
+    for graphs in (False, True):
+        torch.manual_seed(321)
+        m = build(cfg, P, train=True)
+        m.training_graphs = graphs
+        opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.95))
+        losses = []
+        for i, b in enumerate(batches):
+            opt.zero_grad(set_to_none=False)
+            out = m(**b)
+            if graphs and i == 1:
+                with pytest.raises(RuntimeError):
+                    m(**b)  # the graph owns one set of activations
+                lg = out.logits  # filled on access, from the replay's head input
+                assert lg.shape == (4, cfg.max_feats + 40, cfg.vocab_size) and torch.isfinite(lg).all()
+            out.loss.backward()
+            opt.step(clip_max_norm=1.0)
+            losses.append(out.loss.item())
+            if i == 0:  # an eval forward and a step of another shape in between
+                m.eval()
+                with torch.no_grad():
+                    m(**other)
+                m.train()
+        results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, m.step_seed))
+        if graphs:
+            assert len(m.__dict__.get("_train_graphs", {})) == 1
+    (l0, p0, s0), (l1, p1, s1) = results
+    assert s0 == s1 == 3
+    assert all(abs(a - b) < 1e-6 for a, b in zip(l0, l1)), (l0, l1)
+    assert len(set(round(x, 6) for x in l0)) == 3
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
