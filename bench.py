@@ -248,8 +248,22 @@ def main():
         batch.clear(); batch.update(small)
         d = timed(lambda: step(False), n_x)
         batch.clear(); batch.update(keep)
-        extras["host"] = {"enqueue_ms_per_step": d * 1e3, "note": "wall time per step of the same launch sequence at B=1 "
-                          "(GPU work per launch negligible): upper bound of the host cost of a step"}
+        def host_issue_ms(n=4):
+            # what the HOST spends issuing one full-size step: the queue is empty when the step starts and nobody waits for
+            # the GPU afterwards (the label count at the start of forward finds its tiny kernel done at once)
+            tot = 0.0
+            for _ in range(n):
+                sync()
+                t = time.time()
+                step(False)
+                tot += time.time() - t
+            sync()
+            return tot / n * 1e3
+
+        extras["host"] = {"enqueue_ms_per_step": d * 1e3, "issue_ms_per_step": host_issue_ms(),
+                          "note": "enqueue_ms_per_step: wall time per step of the same launch sequence at B=1 (GPU work per launch "
+                                  "negligible: ~1450 dependent launches cost that much on the GPU side too); issue_ms_per_step: "
+                                  "host time to issue one full-size step into an empty queue, nobody waiting for the GPU"}
         # the same step with model.training_graphs (forward and backward replayed as two hipGraphs; clip + Adam eager): GPU
         # time per step, and the host cost where the GPU cannot hide it (B=1, as `host` above)
         model.training_graphs = True
@@ -257,12 +271,13 @@ def main():
         batch.clear(); batch.update(small)
         dh = timed(lambda: step(False), n_x)
         batch.clear(); batch.update(keep)
+        gi = host_issue_ms()
         model.training_graphs = False
         model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
         extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                                  "enqueue_ms_per_step": dh * 1e3,
+                                  "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
                                   "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
-                                          "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step = wall time per step at B=1"}
+                                          "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step as under `host`"}
         if world == 1 and full_cfg:
             # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
             # and with the opt-in one-step-delayed loss check

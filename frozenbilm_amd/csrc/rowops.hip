@@ -687,14 +687,30 @@ __global__ void scatter_rows_f32_kernel(const float* in, const int32_t* rows, in
   for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[c] += in[(long)r * cols + c];
 }
 
-__global__ void sumsq_kernel(const float* x, long n, float* out) {
+// sum of squares, reproducible bit for bit: every block leaves its partial sum in ws[block], a one-block second launch adds
+// the partials in index order (an atomicAdd per block would make the clip factor -- and with it every parameter -- depend
+// on the order in which the blocks happen to finish)
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ void sumsq_kernel(const float* x, long n, float* ws) {
   __shared__ float red[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_fold_kernel(const float* ws, int nblk, float* out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += ws[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += red[0];
 }
 __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                                  float eps, float wd, float bc1, float bc2, const float* sumsq, float max_norm,
@@ -983,10 +999,14 @@ extern "C" int fbl_scatter_rows_f32(const float* in, const int32_t* rows, int R,
   return 0;
 }
 
-extern "C" int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, void* stream) {
+extern "C" int64_t fbl_sumsq_ws_floats(void) { return SUMSQ_BLOCKS; }
+extern "C" int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, float* ws, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n,
-                     out_sumsq);
+  if (!ws || !out_sumsq) return FBL_ERR_ARG;
+  const int nblk = grid1d(n, 256, SUMSQ_BLOCKS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (long)n, ws);
+  FBL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, out_sumsq);
   FBL_CHECK_LAUNCH();
   return 0;
 }

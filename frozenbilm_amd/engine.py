@@ -887,13 +887,13 @@ class Engine:
                 L.adapter_bwd_dw([([seg], self.G[nm + ".up.weight"], self.G[nm + ".down.weight"], self.G[nm + ".down.bias"])
                                   for nm, seg in recs], A=A)
             pend[:] = rest
-        if red is not None:  # a stage is final once every product parked DURING it has been launched (any order: the
+        if red is not None:  # a finished stage is final once none of ITS adapters has a parked product left (any order: the
             # repeated last layer waits one launch longer than the layers behind it, and must not hold their buckets back)
-            parked = [rec[3] for rec in pend]
+            parked = {self._bucket_key(rec[1] + ".up.weight") for rec in pend}
             still = []
-            for key, lo, hi in run.dw_ready_keys:
-                if any(lo <= i < hi for i in parked):
-                    still.append((key, lo, hi))
+            for key in run.dw_ready_keys:
+                if key in parked:
+                    still.append(key)
                 else:
                     red.ready(key)
             run.dw_ready_keys[:] = still
@@ -1039,7 +1039,7 @@ class Engine:
         reducer = self.reducer
 
         red = _Ready(self, run, reducer) if reducer is not None else None
-        run.dw_pending, run.dw_ready_keys, run.dw_count, run.dw_stage_lo = [], [], 0, 0
+        run.dw_pending, run.dw_ready_keys, run.dw_count = [], [], 0
         dq = torch.zeros(N, H, dtype=F32, device=dev)
         Vout = run.Vout
         Vp = _ru(Vout, 64)
@@ -1064,8 +1064,7 @@ class Engine:
             del dlog
 
         def stage_done(key):  # a stage's gradients are final once the adapter products parked in it have been launched
-            run.dw_ready_keys.append((key, run.dw_stage_lo, run.dw_count))
-            run.dw_stage_lo = run.dw_count
+            run.dw_ready_keys.append(key)
             self._dw_flush(run, red)
 
         stage_done("head")

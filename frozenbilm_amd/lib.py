@@ -63,7 +63,8 @@ SIGNATURES = {
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
     "fbl_scatter_rows_f32": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp]),
-    "fbl_sumsq": (_i, [_vp, _l, _vp, _vp]),
+    "fbl_sumsq_ws_floats": (_l, []),
+    "fbl_sumsq": (_i, [_vp, _l, _vp, _vp, _vp]),
     "fbl_adam_flat": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "fbl_cast_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
@@ -586,8 +587,16 @@ def scatter_rows_f32(x, rows, out):
          "fbl_scatter_rows_f32")
 
 
-def sumsq(x, out):
-    _chk(load().fbl_sumsq(_p(x), x.numel(), _p(out), _stream()), "fbl_sumsq")
+_SUMSQ_WS = {}
+
+
+def sumsq(x, out, ws=None):
+    """out[0] += sum x^2 (deterministic: per-block partials in `ws`, a per-device buffer of this binding by default)"""
+    if ws is None:
+        ws = _SUMSQ_WS.get(x.device)
+        if ws is None:
+            ws = _SUMSQ_WS[x.device] = torch.empty(load().fbl_sumsq_ws_floats(), dtype=torch.float32, device=x.device)
+    _chk(load().fbl_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "fbl_sumsq")
 
 
 def adam_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0):

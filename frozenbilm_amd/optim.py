@@ -41,17 +41,19 @@ class FusedAdam(torch.optim.Optimizer):
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
             self._ss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._ss_ws = torch.empty(L.load().fbl_sumsq_ws_floats(), dtype=torch.float32, device=flat.device)
         elif self._m.numel() != flat.numel():
             raise RuntimeError("the trainable set changed size under a live optimizer state")
         elif self._m.device != flat.device:  # the model moved: the moments follow it
             self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)
             self._ss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._ss_ws = torch.empty(L.load().fbl_sumsq_ws_floats(), dtype=torch.float32, device=flat.device)
         grp = self.param_groups[0]
         self._step += 1
         ss = None
         if clip_max_norm and clip_max_norm > 0:
             self._ss.zero_()
-            L.sumsq(g, self._ss)
+            L.sumsq(g, self._ss, ws=self._ss_ws)
             ss = self._ss
         b1, b2 = grp["betas"]
         L.adam_flat(flat, g, self._m, self._v, grp["lr"], b1, b2, grp["eps"], grp["weight_decay"], self._step, sumsq_t=ss,

@@ -308,7 +308,9 @@ int fbl_scatter_rows_f32(const float* in, const int32_t* rows, int R, int cols, 
 /* Fused multi-tensor Adam over ONE flat fp32 buffer (all trainable params are views into it) with the global-norm
  * clip folded in: g *= min(1, max_norm/(norm+1e-6)) where norm = sqrt(sumsq[0]).
  * ref: main.py:82-84 (clip_grad_norm_ + torch.optim.Adam.step, betas (0.9,0.95), eps 1e-8, wd 0). */
-int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, void* stream); /* out[0] += sum x^2 */
+int64_t fbl_sumsq_ws_floats(void);
+/* out[0] += sum x^2, reproducible bit for bit (per-block partials in ws[>= fbl_sumsq_ws_floats()], folded in index order) */
+int fbl_sumsq(const float* x, int64_t n, float* out_sumsq, float* ws, void* stream);
 int fbl_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale,
                   void* stream);

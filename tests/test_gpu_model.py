@@ -804,13 +804,13 @@ def test_operands_follow_hidden_parameter_writes_unless_frozen():
         assert abs(l1 - l0) > 1e-4, "the forward still ran on the old adapter weights"
         with m.weights_frozen():
             l2 = m(**batch).loss.item()  # first forward in the scope rebuilds
-            assert l2 == l1
+            assert abs(l2 - l1) < 1e-5  # (the loss is summed with atomics: equal up to the order of its terms)
             p.data.mul_(1.0 / 3.0)  # breaks the promise: the scope keeps the packed operands
-            assert m(**batch).loss.item() == l1
+            assert abs(m(**batch).loss.item() - l1) < 1e-5
             p.mul_(1.0)  # a write through the parameter object bumps its version counter: seen
             l3 = m(**batch).loss.item()
-            assert abs(l3 - l0) < 1e-6
-        assert abs(m(**batch).loss.item() - l0) < 1e-6
+            assert abs(l3 - l0) < 1e-5
+        assert abs(m(**batch).loss.item() - l0) < 1e-5
 
 
 def test_delayed_loss_check_gives_the_same_epoch_statistics():
@@ -846,7 +846,7 @@ def test_delayed_loss_check_gives_the_same_epoch_statistics():
         finals.append(m.get_param("deberta.embeddings.linear_video.weight").detach().clone())
     assert set(stats_out[0]) == set(stats_out[1])
     for k in stats_out[0]:
-        assert abs(stats_out[0][k] - stats_out[1][k]) < 1e-6, (k, stats_out)
+        assert abs(stats_out[0][k] - stats_out[1][k]) < 1e-5, (k, stats_out)
     assert torch.equal(finals[0], finals[1])
 
 

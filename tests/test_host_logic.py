@@ -147,8 +147,8 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
     nL = 8
     names = lambda li: [f"layer.{li}.a1", f"layer.{li}.a2"]
     G = {n + sfx: n for li in range(nL) for n in names(li) for sfx in (".up.weight", ".down.weight", ".down.bias")}
-    eng = types.SimpleNamespace(dw_group=6, G=G)
-    run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0, dw_stage_lo=0)
+    eng = types.SimpleNamespace(dw_group=6, G=G, _bucket_key=lambda n: "layer" + n.split(".")[1])
+    run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0)
     ready = []
     red = types.SimpleNamespace(ready=ready.append)
 
@@ -158,8 +158,7 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
             run.dw_count += 1
 
     def stage_done(key):
-        run.dw_ready_keys.append((key, run.dw_stage_lo, run.dw_count))
-        run.dw_stage_lo = run.dw_count
+        run.dw_ready_keys.append(key)
         E.Engine._dw_flush(eng, run, red)
 
     stage_done("head")
