@@ -25,6 +25,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._step = 0
         self._ss = None
+        self._ss_ws = None
 
     def zero_grad(self, set_to_none: bool = True):
         eng = self.model._engine
@@ -53,6 +54,8 @@ class FusedAdam(torch.optim.Optimizer):
         ss = None
         if clip_max_norm and clip_max_norm > 0:
             self._ss.zero_()
+            if self._ss_ws is None or self._ss_ws.device != g.device:
+                self._ss_ws = torch.empty(L.load().fbl_sumsq_ws_floats(), dtype=torch.float32, device=g.device)
             L.sumsq(g, self._ss, ws=self._ss_ws)
             ss = self._ss
         b1, b2 = grp["betas"]
