@@ -25,6 +25,10 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 if DEBUG:
     FLAGS.append("-DFBL_DEBUG_SWITCHES")
+    FLAGS += os.environ.get("FBL_DEBUG_EXTRA_FLAGS", "").split()  # e.g. -DFBL_NO_SEED_DEV (A/B of code-generation effects)
+    if os.environ.get("FBL_DEBUG_LIB_NAME"):
+        LIB = os.path.join(HERE, os.environ["FBL_DEBUG_LIB_NAME"])
+        OBJ = os.path.join(HERE, "csrc", "build_dbg_" + os.path.splitext(os.environ["FBL_DEBUG_LIB_NAME"])[0])
 
 
 def _hipcc() -> str:

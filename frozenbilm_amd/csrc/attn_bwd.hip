@@ -150,11 +150,13 @@ struct BwdAArgs {
   const bf16* pk; const bf16* pq; long ldp;
   const int16_t* relidx; const int32_t* mask; const int32_t* klen; const int32_t* border;
   const float* lse; const float* Dv;                      // [B,nh,S]
-  float scale, p_drop; uint64_t seed; const uint64_t* seed_dev;
+  float scale, p_drop; uint64_t seed;
   bf16* dV; long lddv;                                    // row-major out, head h at col h*64
   bf16* dS; bf16* dST;                                    // [B,nh,Sp,Sp]
   int B, S, Sp, nh, span2;
   int lin;  // |d| < lin: idx(d) = idx(0) + d (identity buckets); 0 = unknown
+  const uint64_t* seed_dev;  // optional device word added to seed (fbl_seed); last: the offsets of the fields above are what the
+                             // register allocation of this kernel was tuned with (any field in front of them costs spills)
 };
 
 // LDS: Q, dO tiles (per iteration) and this workgroup's K tile 3 x 8 KiB, T1 / T2 2 x 13 KiB (reused as the dS / dS^T
@@ -178,6 +180,10 @@ struct ATileRegs {
   float lse, D;
 };
 
+// DEVSEED: the dropout seed gets the device word added (launch graphs).  Two instantiations on purpose: this kernel sits at
+// its register cap, and the scalar load + add in front of the key derivation costs the common (DEVSEED = false) launch
+// 24 more bytes of spills per lane and 14 % of its time (120 -> 136 us, same box) if it shares one body with it.
+template <bool DEVSEED>
 __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   f32x4 dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const DropKey dk = attn_drop_key(a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0, b * a.nh + h, a.p_drop);
+  const DropKey dk = attn_drop_key(DEVSEED ? a.seed + *a.seed_dev : a.seed, b * a.nh + h, a.p_drop);
   const float k2 = a.scale * LOG2E;
   const long sbase = ((long)b * a.nh + h) * Sp * Sp;
   const int izero = a.relidx[S - 1];  // idx(0)
@@ -668,17 +674,22 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
   if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
-  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, seed_dev, (bf16*)dV, lddv,
-             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span};
+  BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
+             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span, seed_dev};
   attn_debug_init();
   const int smem_bytes = a_total(Sp);
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem_bytes;
   }
-  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3((unsigned)(Sp / 64) * nh * B), dim3(256), smem_bytes, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(Sp / 64) * nh * B);
+  if (seed_dev && p_drop > 0.f)
+    hipLaunchKernelGGL(attn_bwd_ds_kernel<true>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_ds_kernel<false>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

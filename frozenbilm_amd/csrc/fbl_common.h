@@ -88,7 +88,11 @@ __device__ __forceinline__ float fbl_dropout_scale(uint64_t seed, uint64_t idx, 
 // captured launch (hipGraph replay) draws a new mask every time the host advances it -- the seed itself is a kernel argument
 // and frozen into the graph.  NULL: the launch-time value alone.
 __device__ __forceinline__ uint64_t fbl_seed(uint64_t seed, const uint64_t* seed_dev) {
+#ifdef FBL_NO_SEED_DEV  // (measurement builds only: what the device word costs a kernel's code generation)
+  return seed;
+#else
   return seed_dev ? seed + *seed_dev : seed;
+#endif
 }
 // host+device: p -> 32-bit threshold (drop iff hash < thresh)
 static inline __host__ __device__ uint32_t fbl_drop_thresh(float p) {

@@ -451,16 +451,14 @@ class Engine:
             rows_labelled = torch.nonzero(full_labels != -100).view(-1)
         if train:
             m.step_seed += 1
-        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=0,
+        # Dropout seeds = a per-site constant (a function of the site index only) + the position of this step in the model's
+        # mask stream.  Eager launches add the two on the host (Run.next_seed); a captured launch sequence keeps the per-site
+        # constants as kernel arguments and reads the position from a device word (train_graph.py; include/fbl.h "Dropout
+        # seeds") -- the same sum, so eager and replayed steps draw identical masks.
+        run = Run(B=B, S=S, T=T, Lt=Lt, train=train, save=need_grad, seed_base=self.seed_word_value() if train else 0,
                   p_hid=self.cfg.hidden_dropout_prob if train else 0.0,
                   p_att=self.cfg.attention_probs_dropout_prob if train else 0.0,
                   p_ad=m.adapter_dropout if train else 0.0)
-        if train:
-            # Dropout seeds = a per-site constant (Run.next_seed: a function of the site index only, so that a captured
-            # launch sequence stays valid) + this device word, the position of the step in the model's mask stream
-            # (include/fbl.h "Dropout seeds").  One word per Run: a backward pass regenerates the masks of ITS forward, however
-            # many forwards ran in between.
-            run.seed_word = torch.full((1,), self.seed_word_value(), dtype=torch.int64, device=self.dev)
         run.mask = mask.view(-1)
         run.want_attn = bool(want_attn)
         if want_attn and train and run.p_att > 0:
@@ -1204,7 +1202,8 @@ class Run:
 
     def next_seed(self) -> int:
         self._site += 1
-        return (self.seed_base * 0x9E3779B1 + self._site * 0x85EBCA77) & 0xFFFFFFFFFFFF  # (+ the device word, in the kernel)
+        # seed_base: the step's position in the mask stream (eager) or 0 (captured: the device word carries it; Run.seed_word)
+        return (self.seed_base + self._site * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
 
 
 class _StepFn(torch.autograd.Function):

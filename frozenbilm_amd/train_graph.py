@@ -11,8 +11,9 @@ ONE private memory pool: the backward reads the activations the forward left in 
     optimizer.step(...)         # stays eager: two launches whose arguments (lr, Adam step) change every step
 
 What had to move for this:
-  * dropout seeds are per-site constants + a device word (include/fbl.h "Dropout seeds"): the word of the captured pass is
-    rewritten before every replay, the kernel arguments frozen into the graph never change;
+  * dropout seeds are per-site constants + the step's position in the mask stream; eager launches add the two on the host,
+    captured launches keep the constants as (frozen) kernel arguments and read the position from a device word that is
+    rewritten before every replay (include/fbl.h "Dropout seeds"): the same sums, hence the same masks;
   * the list of labelled rows has a fixed capacity per graph (next multiple of 256): the host still counts the labels at the
     start of the step -- on an input, as the eager path does -- and pads the list with an unlabelled row, whose loss term and
     gradient are exactly zero (fbl_ce_fwd / fbl_ce_bwd_rows ignore labels < 0);
@@ -157,11 +158,9 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
     if R == 0:
         return None
     r_cap = min(N, -(-R // ROW_BUCKET) * ROW_BUCKET)
-    if r_cap > R:
-        free = torch.nonzero(flat == -100).view(-1)
-        if free.numel() == 0:
-            return None
-        rows = torch.cat([rows, free[:1].expand(r_cap - R)])
+    if r_cap > R:  # pad with the first unlabelled row (found on the device: no second synchronisation; R < N: one exists)
+        free = torch.argmax((flat == -100).to(torch.int8)).view(1)
+        rows = torch.cat([rows, free.expand(r_cap - R)])
     key = (id(eng), B, Lt, T, "video_mask" in feed, r_cap, tuple(sorted((k, str(v.dtype)) for k, v in feed.items())))
     cache = model.__dict__.setdefault("_train_graphs", {})
     step = cache.pop(key, None)
