@@ -230,7 +230,8 @@ def main():
             with torch.no_grad():
                 return model(**batch).loss
 
-        d = timed(fwd_only, n_x)
+        with model.weights_frozen():  # as main.evaluate runs it: nothing writes to the parameters between these forwards
+            d = timed(fwd_only, n_x)
         model.train()
         rows_lab = float((batch["labels"] != -100).sum().item()) / B
         ex_f, ex_b = executed_flops_per_sample(S=S, rows_labelled=rows_lab, layers=args.layers)

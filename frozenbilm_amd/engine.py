@@ -77,6 +77,8 @@ class Engine:
         self._build_flat()
         self._pack_frozen()
         self._relidx: Dict[int, torch.Tensor] = {}
+        self._pos_cache: Dict[int, torch.Tensor] = {}  # per-layer position projections of inference forwards (_pos_proj_cached)
+        self._no_pos_cache = False  # set while an inference graph is captured: a replay must not depend on state kept outside it
         self.reducer = None  # set by parallel.GradReducer for data-parallel training
         self._pad_bufs = {}
         self.params_version = 0  # bumped by FusedAdam.step (which updates the flat buffer through raw pointers)
@@ -290,6 +292,7 @@ class Engine:
 
     def refresh_trainable_operands(self):
         """bf16 MFMA operands of the trainable matrices (they change every optimizer step)."""
+        self._pos_cache.clear()
         L.cast_bf16(self.flat, self.flat_bf16)
         H = self.H
         self.ad = []
@@ -584,6 +587,17 @@ class Engine:
         return (Stream(bf16=full[:N], norm=NormRef(t, stats, g, b, None), full=full if tail else None), ob, z, seed_ad,
                 seed_ln)
 
+    def _pos_proj_cached(self, li: int, W, Rb: torch.Tensor) -> torch.Tensor:
+        """[PQ|PK] = R.[Wq;Wk]^T + b of layer `li` ([2*span, 2H] bf16, model/deberta.py:847-853) for inference forwards inside
+        model.weights_frozen(): R = LayerNorm_enc(rel_embeddings) only changes with the trainable parameters, and every
+        rebuild of their operands (refresh_trainable_operands) drops this cache."""
+        c = self._pos_cache.get(li)
+        if c is None:
+            c = torch.empty(self.span2, 2 * self.H, dtype=BF16, device=self.dev)
+            L.gemm(Rb, W["Wqkv"][: 2 * self.H], bias=W["bqkv"][: 2 * self.H], out_bf16=c)
+            self._pos_cache[li] = c
+        return c
+
     def _layer_fwd(self, run, li: int, kv: Stream, q: Optional[Stream], Rb: torch.Tensor):
         """One execution of encoder layer ``li`` (model/deberta.py:351-375); q != None is the EMD form where the
         query stream (and the attention residual, :290-292) differs from the key/value stream."""
@@ -605,15 +619,39 @@ class Engine:
             else:
                 full[N:].copy_(Rb)
 
-        qkv = torch.empty(N + P_, 3 * H, dtype=BF16, device=dev)
-        put_r(kv.full)
-        if q is None:
-            L.gemm(kv.full, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
+        # Inference shortcuts (no gradient bookkeeping, no position dropout -- results are bit-identical to the general path):
+        #  * inside model.weights_frozen() the position projections [PQ|PK] of a layer are the same in every forward: computed
+        #    once per layer and kept (dropped whenever the trainable operands are rebuilt), the QKV GEMM then has N rows;
+        #  * the second pass of the enhanced mask decoder projects the SAME key/value stream with the same weights as the
+        #    first (model/deberta.py:1395-1408): only its query projection is new, written over the first pass's Q columns.
+        infer = not run.save and run.p_hid == 0
+        pqk_c = (self._pos_proj_cached(li, W, Rb)
+                 if infer and getattr(self.m, "_weights_frozen", 0) > 0 and not self._no_pos_cache else None)
+        reuse = infer and q is not None and getattr(run, "emd_qkv", None) is not None
+        if reuse:
+            qkv = run.emd_qkv
+            if pqk_c is None:
+                put_r(q.full)
+            L.gemm(q.full if pqk_c is None else q.bf16, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
         else:
-            put_r(q.full)
-            L.gemm(q.full, W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
-            L.gemm(kv.full, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
-        pq, pk = qkv[N:, :H], qkv[N:, H:2 * H]
+            rows_in = N if pqk_c is not None else N + P_
+            qkv = torch.empty(rows_in, 3 * H, dtype=BF16, device=dev)
+            kin = kv.full[:rows_in]
+            if pqk_c is None:
+                put_r(kv.full)
+            if q is None:
+                L.gemm(kin, W["Wqkv"], bias=W["bqkv"], out_bf16=qkv)
+            else:
+                if pqk_c is None:
+                    put_r(q.full)
+                L.gemm(q.full[:rows_in], W["Wqkv"][:H], bias=W["bqkv"][:H], out_bf16=qkv[:, :H])
+                L.gemm(kin, W["Wqkv"][H:], bias=W["bqkv"][H:], out_bf16=qkv[:, H:])
+                if infer:
+                    run.emd_qkv = qkv
+        if pqk_c is not None:
+            pq, pk = pqk_c[:, :H], pqk_c[:, H:]
+        else:
+            pq, pk = qkv[N:, :H], qkv[N:, H:2 * H]
         ctx = torch.empty(N, H, dtype=BF16, device=dev)
         lse = torch.empty(B, nh, S, dtype=F32, device=dev)
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
@@ -642,7 +680,7 @@ class Engine:
             run, li, h, W, "Wd", "bd", ad.get("a2"), self.A2, self.merge2, N, p + ".output.LayerNorm",
             resid=Stream(bf16=a.bf16, norm=a.norm), tail=self.span2)
         if run.save:
-            sv.qkv, sv.pqk, sv.ctx, sv.lse = qkv[:N], qkv[N:, : 2 * H], ctx, lse
+            sv.qkv, sv.pqk, sv.ctx, sv.lse = qkv[:N], qkv[N:, : 2 * H], ctx, lse  # (run.save: never the inference shortcuts)
             sv.ob, sv.z1, sv.ln1 = ob, z1, a.norm
             sv.hpre, sv.fb, sv.z2, sv.ln2 = hpre, fb, z2, out.norm
             run.layers.append(sv)
@@ -709,16 +747,21 @@ class Engine:
         # ---- MLM head (:1544-1558): LN(gelu(dense(x))) . table^T + bias
         hin = q.bf16
         rows_only = getattr(run, "logit_rows", None)
+        # an inference forward that is only asked for the loss (evaluate, main.py:139) runs the head's dense + GELU +
+        # LayerNorm on the labelled rows only, like the vocabulary GEMM below; fill_logits redoes it on every row if the
+        # logits are read after all
+        loss_rows = (rows_only is None and run.labels is not None and not run.save and not self.eager_logits
+                     and 0 < run.rows.numel() < N)
+        n_all = N
+        if loss_rows:
+            run.head_in_all = q.bf16
+            rows_only = run.rows.to(torch.int32)
         if rows_only is not None:  # inference on selected token rows (the [MASK] rows of videoqa.py:164-168 / mc.py:166-170)
             N = rows_only.numel()
             hin = torch.empty(N, H, dtype=BF16, device=dev)
             if N:
                 L.gather_rows_bf16(q.bf16, rows_only, hin)
-        hp = torch.empty(N, H, dtype=F32, device=dev)
-        L.gemm(hin, self.Wh, bias=self.bh, out_f32=hp)
-        hg = torch.empty(N, H, dtype=F32, device=dev)
-        L.dropout_gelu_fwd(hp, 0.0, 0, hg)
-        hl, _ = self._ln(run, "lm_predictions.lm_head.LayerNorm", y=hg, resid=None, N=N)
+        hp, hl = self._head_stage(run, hin, N)
         run.head_pre, run.head_norm, run.head_ln_bf16 = hp, hl.norm, hl.bf16
         if use_ans:
             Vout, table, bias = self.n_ans, self.Ansb, self.ans_bias
@@ -737,8 +780,11 @@ class Engine:
             R = rows.numel()
             run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
             if R > 0:
-                hrows = torch.empty(R, H, dtype=BF16, device=dev)
-                L.gather_rows_bf16(hl.bf16, run.rows_i32, hrows)
+                if loss_rows:
+                    hrows = hl.bf16  # the head already ran on exactly these rows
+                else:
+                    hrows = torch.empty(R, H, dtype=BF16, device=dev)
+                    L.gather_rows_bf16(hl.bf16, run.rows_i32, hrows)
                 lc = torch.empty(R, ldv, dtype=F32, device=dev)
                 L.gemm(hrows, table, bias=bias, out_f32=lc, N=Vout)
                 run.labels_c = run.labels[rows].contiguous()
@@ -746,7 +792,7 @@ class Engine:
                 L.ce_fwd(lc, run.labels_c, Vout, run.row_lse, run.loss_acc)
                 run.logits_c = lc
             loss_t = run.loss_acc[0] / run.loss_acc[1]  # mean over labelled rows (CrossEntropyLoss, :1483-1488)
-            run.logits = torch.empty(N, ldv, dtype=F32, device=dev)
+            run.logits = torch.empty(n_all, ldv, dtype=F32, device=dev)
             run.logits_pending = True
             if self.eager_logits:
                 self.fill_logits(run)
@@ -761,7 +807,20 @@ class Engine:
         the storage of the tensor already handed out (and already wired into the autograd node), on the current stream."""
         if getattr(run, "logits_pending", False):
             run.logits_pending = False
+            hin_all = getattr(run, "head_in_all", None)
+            if hin_all is not None:  # the forward ran the head on the labelled rows only: now on every row
+                _, hl = self._head_stage(run, hin_all, hin_all.shape[0])
+                run.head_ln_bf16, run.head_in_all = hl.bf16, None
             L.gemm(run.head_ln_bf16, run.head_table, bias=run.head_bias, out_f32=run.logits, N=run.Vout)
+
+    def _head_stage(self, run, hin, N):
+        """prediction head in front of the vocabulary GEMM (model/deberta.py:1544-1552): LayerNorm(gelu(dense(x)))"""
+        hp = torch.empty(N, self.H, dtype=F32, device=self.dev)
+        L.gemm(hin, self.Wh, bias=self.bh, out_f32=hp)
+        hg = torch.empty(N, self.H, dtype=F32, device=self.dev)
+        L.dropout_gelu_fwd(hp, 0.0, 0, hg)
+        hl, _ = self._ln(run, "lm_predictions.lm_head.LayerNorm", y=hg, resid=None, N=N)
+        return hp, hl
 
     def _materialize(self, s: Stream, add=None, S=1, out_f32=None, out_bf16=None):
         N, H = s.bf16.shape

@@ -400,10 +400,11 @@ class DebertaV2ForMaskedLM(nn.Module):
                 return eng.run(static["input_ids"], static["attention_mask"], static.get("video"), static.get("video_mask"),
                                None, mlm, False, logit_rows=static["rows"])["logits"]
 
-            run_once()  # warm-up outside the capture (lazy initialisation, allocator)
-            torch.cuda.synchronize(eng.dev)
-            graph = torch.cuda.CUDAGraph()
-            try:
+            eng._no_pos_cache = True  # the captured forward recomputes the position projections: it reads nothing that a later
+            try:                      # rebuild of the trainable operands would re-allocate behind its back
+                run_once()  # warm-up outside the capture (lazy initialisation, allocator)
+                torch.cuda.synchronize(eng.dev)
+                graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     logits = run_once()
             except Exception as e:  # noqa: BLE001
@@ -413,6 +414,8 @@ class DebertaV2ForMaskedLM(nn.Module):
                 warnings.warn(f"inference graph capture failed ({type(e).__name__}: {e}); staying on the eager path")
                 self.inference_graphs = False
                 return None
+            finally:
+                eng._no_pos_cache = False
             ent = (graph, static, logits)
         graph, static, logits = ent
         cache[key] = ent  # most recently used last

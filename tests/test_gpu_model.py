@@ -894,3 +894,38 @@ def test_graphed_training_step_equals_the_eager_step():
     assert len(set(round(x, 6) for x in l0)) == 3
     for n in p0:
         assert torch.equal(p0[n], p1[n]), n
+
+
+def test_inference_shortcuts_change_nothing():
+    """Inference forwards inside model.weights_frozen() keep the per-layer position projections across forwards, reuse the
+    key/value projection of the first enhanced-mask-decoder pass in the second and, when only a loss is asked for, run the
+    prediction head on the labelled rows: same loss, same logits (filled on access) as the general path; a parameter update
+    in between is seen; the [MASK]-row path (logit_rows) agrees as well."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=53, std=0.05, ln_jitter=0.1)
+    m = build(cfg, P, train=False)
+    batch = to_dev(synth_batch(cfg, B=3, L=30, seed=12))
+    S = cfg.max_feats + 30
+    rows = torch.tensor([0 * S + 12, 1 * S + 15, 2 * S + 20], device=DEV)
+    feed = {k: v for k, v in batch.items() if k != "labels"}
+    with torch.no_grad():
+        ref = m(**batch)
+        ref_loss, ref_logits = ref.loss.item(), ref.logits.clone()
+        ref_rows = m(**feed, logit_rows=rows).logits.clone()
+        with m.weights_frozen():
+            for it in range(3):  # first forward fills the position cache, the next ones use it
+                out = m(**batch)
+                assert abs(out.loss.item() - ref_loss) < 1e-5
+            assert len(m.engine()._pos_cache) == cfg.num_hidden_layers
+            assert (out.logits - ref_logits).abs().max().item() < 1e-5  # head on every row, on access
+            assert (m(**feed, logit_rows=rows).logits - ref_rows).abs().max().item() < 1e-5
+            # an update through the parameter object is seen: cache dropped, new values used
+            p = m.get_param("deberta.encoder.LayerNorm.weight")
+            p.mul_(1.5)
+            l2 = m(**batch).loss.item()
+            p.mul_(1.0 / 1.5)
+        general = m(**batch).loss.item()  # outside the scope: the general path
+        p.mul_(1.5)
+        l2_general = m(**batch).loss.item()
+        p.mul_(1.0 / 1.5)
+    assert abs(general - ref_loss) < 1e-5 and abs(l2 - l2_general) < 1e-5 and abs(l2 - ref_loss) > 1e-6
