@@ -173,9 +173,13 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
         # one eager step of this shape first: lazy initialisations (kernel attributes, workspaces, allocator warm-up) happen
         # outside the capture.  It leaves no trace: the caller's accumulated gradients and the mask-stream position are restored.
         saved = eng.flat_grad.clone()
-        res = eng.run(feed["input_ids"], feed["attention_mask"], feed.get("video"), feed.get("video_mask"), feed["labels"],
-                      False, False)
-        res["loss"].backward()
+        red, eng.reducer = eng.reducer, None  # (no collectives: ranks may capture at different steps -- their row capacities differ)
+        try:
+            res = eng.run(feed["input_ids"], feed["attention_mask"], feed.get("video"), feed.get("video_mask"), feed["labels"],
+                          False, False)
+            res["loss"].backward()
+        finally:
+            eng.reducer = red
         eng.flat_grad.copy_(saved)
         del res, saved
         torch.cuda.synchronize(dev)
