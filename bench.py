@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--eval-forward", action="store_true", help="time the eval forward only (reported under its own metric)")
     ap.add_argument("--full-logits", action="store_true", help="read .logits in every timed step (reference-eager head)")
     ap.add_argument("--no-extras", action="store_true", help="skip the with_full_logits / eval_forward / host side measurements")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic (two short rocprofv3 --pmc child runs of this script); the newest "
+                         "committed profiles/*_traffic.json is reported instead")
+    ap.add_argument("--prewarm", type=int, default=PREWARM_STEPS, help=argparse.SUPPRESS)
     ap.add_argument("--no-inference-graphs", action="store_true",
                     help="downstream workloads: leave the loops' opt-in args.inference_graphs off (eager launches)")
     ap.add_argument("--workload", default="mlm", choices=["mlm", "videoqa", "mc"],
@@ -162,7 +166,7 @@ def main():
     # clock / power-state ramp: a box that has just been handed over can sit in a low-power state for the first second of
     # load (one round-1 run measured 2x slower end to end for that reason), so a fixed untimed pre-warm precedes the W
     # warm-up steps the contract asks for
-    for _ in range(PREWARM_STEPS):
+    for _ in range(args.prewarm):
         step()
     for _ in range(args.warmup):
         loss = step()
@@ -197,6 +201,10 @@ def main():
     if not args.no_roofline:
         # every rank replays the instrumented steps (they contain the gradient collectives); rank 0 reports its own
         roofline = measure_gemm_roofline(L, step)
+        if rank == 0 and world == 1 and not args.no_traffic and not args.eval_forward:
+            live = measure_traffic_live(args)
+            if live is not None:
+                roofline.update(live)
         roofline["whole_step_algorithmic_tflops"] = whole_step_tflops
         roofline["whole_step_frac_of_peak"] = whole_step_tflops / PEAK_BF16_TFLOPS
         sync()
@@ -611,6 +619,61 @@ def measure_gemm_roofline(L, step_fn):
             "gemm_ms_per_step": tot_ms, "executed_gemm_tflops_per_step": tot_fl / 1e12,
             "top_shapes_MNKb_count_ms_tflops": [[list(k), v[0], round(v[1], 3), round(v[2] / (v[1] * 1e-3) / 1e12, 1)]
                                                 for k, v in top]}
+
+
+def measure_traffic_live(args):
+    """roofline.traffic measured by THIS run: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc
+    WRITE_SIZE` (separate passes, kernel-trace only -- never combined with other trace domains; MI355X_MICROARCH.md, HBM section:
+    FETCH_SIZE in KiB, doubled on gfx950), a few steps each, summed over the gemm8_kernel launches.  Returns None -- the caller keeps
+    the committed figure -- when rocprofv3 is missing, a pass fails or takes longer than its time-out."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    here = os.path.abspath(__file__)
+    steps = 3  # instrumented steps per pass: 2 pre-warm + 1 timed
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    launches = 0
+    whole = 0.0
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, c)
+                cmd = [exe, "--pmc", c, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable, here, "--steps", "1", "--warmup",
+                       "0", "--prewarm", "2", "--batch", str(args.batch), "--text-len", str(args.text_len), "--layers", str(args.layers),
+                       "--no-cpu-baseline", "--no-roofline", "--no-extras", "--no-traffic"]
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
+                if r.returncode != 0 or not dbs:
+                    return None
+                cur = sqlite3.connect(dbs[0]).cursor()
+                cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+                ix = {k: i for i, k in enumerate(cols)}
+                n = 0
+                for row in cur.execute("select * from counters_collection").fetchall():
+                    if row[ix["counter_name"]] != c:
+                        continue
+                    byts = float(row[ix["value"]]) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+                    whole += byts
+                    if "gemm8_kernel" in str(row[ix.get("kernel_name", ix.get("name", 0))]):
+                        tot[c] += byts
+                        n += 1
+                launches = n if c == "FETCH_SIZE" else launches
+    except Exception:  # noqa: BLE001  (time-out, missing tables, ...): keep the committed figure
+        return None
+    if launches == 0:
+        return None
+    return {"traffic": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches,
+            "traffic_source": "measured by this run: two child runs of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                              "(kernel-trace only), %d steps each; FETCH_SIZE x2 for gfx950; bytes per gemm8_kernel launch over %d "
+                              "launches; whole step %.1f GB" % (steps, launches, whole / steps / 1e9),
+            "traffic_gemm8_gb_per_step": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps / 1e9,
+            "traffic_whole_step_gb": whole / steps / 1e9}
 
 
 def _takes_gemm8(M, N, K):

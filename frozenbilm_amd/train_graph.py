@@ -123,7 +123,11 @@ class GraphedStep:
     def run_backward(self, gloss):
         eng = self.eng
         self.gloss.copy_(gloss.detach().to(F32).reshape(()))
-        eng.attach_grads()
+        first, last = eng.named[eng.order[0]], eng.named[eng.order[-1]]
+        if not (first.grad is not None and last.grad is not None and first.grad.data_ptr() == eng.G[eng.order[0]].data_ptr()
+                and last.grad.data_ptr() == eng.G[eng.order[-1]].data_ptr()):
+            eng.attach_grads()  # (300 parameters: skipped while p.grad still are the views of the flat buffer -- zero_grad
+            #                      (set_to_none=True) or a foreign .grad on either end brings the full pass back)
         self.g_bwd.replay()
         self.pending_backward = False
         if eng.reducer is not None:
