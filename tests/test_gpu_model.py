@@ -167,7 +167,7 @@ def test_backward_vs_oracle_larger_batch():
     print("worst relative Frobenius grad errors:", worst[:8])
     strict = [w for w in worst if "adapter.down" not in w[1]]
     assert strict[0][0] < 4e-2, strict[:6]
-    assert worst[0][0] < 0.25, worst[:6]  # ReLU-gate flips, see test_tiny_backward_golden
+    assert worst[0][0] < 0.18, worst[:6]  # ReLU-gate flips, see test_tiny_backward_golden (measured 12.5 %; the rest < 4 %)
 
 
 def test_answer_head_golden(golden):
@@ -268,7 +268,7 @@ def test_xlarge_golden(golden):
     assert abs(out.loss.item() - g["loss"].item()) < 2e-2
     agree = (lg.argmax(-1).cpu() == g["argmax"]).float().mean().item()
     print("argmax agreement", agree)
-    assert agree > 0.93
+    assert agree > 0.99  # measured 0.998 - 1.000 (rounds 3 / 4)
 
 
 def test_max_length_s512_forward_backward_vs_oracle():
@@ -469,7 +469,7 @@ def test_xlarge_backward_golden(golden):
     assert sorted(names) == sorted(got)
     norm_err = sorted(((abs(got[n].double().norm().item() - r) / max(r, 1e-30), n) for n, r in zip(names, g["norms"])), reverse=True)
     print("worst gradient-norm errors:", [(round(e, 4), n) for e, n in norm_err[:6]])
-    assert norm_err[0][0] < 0.04, norm_err[:6]  # measured: 1.9 % worst (an adapter.down tensor), < 1 % for the rest
+    assert norm_err[0][0] < 0.03, norm_err[:6]  # measured: 1.8 - 2.05 % worst (an adapter.down tensor), < 1 % for the rest
     bad, worst = [], []
     for k in g:
         if not k.startswith("grad."):
@@ -481,7 +481,7 @@ def test_xlarge_backward_golden(golden):
         worst.append((round(fro, 4), n))
         # adapter.down: ReLU-gate flips against the pure-fp32 reference (measured <= 12.5 %; the gate-matched test above
         # holds the same tensors to 2 %); everything else measured <= 3.7 %
-        if fro > (0.2 if "adapter.down" in n else 5e-2):
+        if fro > (0.17 if "adapter.down" in n else 5e-2):  # measured 12.2 - 12.9 % / 4.0 %
             bad.append((n, round(fro, 4)))
     worst.sort(reverse=True)
     print("worst relative Frobenius errors on the stored slices:", worst[:8])
