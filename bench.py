@@ -99,6 +99,8 @@ def main():
                     help="do not re-measure roofline.traffic (two short rocprofv3 --pmc child runs of this script); the newest "
                          "committed profiles/*_traffic.json is reported instead")
     ap.add_argument("--prewarm", type=int, default=PREWARM_STEPS, help=argparse.SUPPRESS)
+    ap.add_argument("--training-graphs", action="store_true",
+                    help="time the step with model.training_graphs = True (reported in config; for profiling the replayed step)")
     ap.add_argument("--no-inference-graphs", action="store_true",
                     help="downstream workloads: leave the loops' opt-in args.inference_graphs off (eager launches)")
     ap.add_argument("--workload", default="mlm", choices=["mlm", "videoqa", "mc"],
@@ -107,6 +109,8 @@ def main():
     args = ap.parse_args()
     if args.workload != "mlm":
         return run_downstream(args)
+    if args.training_graphs:  # (a replayed step issues no launches the roofline instrumentation could bracket)
+        args.no_roofline = args.no_extras = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -137,6 +141,7 @@ def main():
     model = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1)
     model.to(dev)
     model.train(not args.eval_forward)
+    model.training_graphs = bool(args.training_graphs)
     eng = model.engine()
     opt = FusedAdam(model, lr=3e-5, betas=(0.9, 0.95))
     # FBL_FORCE_REDUCER=1 exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
@@ -294,7 +299,9 @@ def main():
             extras["train_one_epoch"] = {"note": "frozenbilm_amd.main.train_one_epoch over synthetic batches that start on the "
                                                  "host (CPU mask_tokens, H2D copies, loss logging): the loop, not the step body",
                                          "reference_order": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False),
-                                         "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True)}
+                                         "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True),
+                                         "reference_order_graphed": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False,
+                                                                                       graphs=True)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -323,7 +330,8 @@ def main():
                        "head": ("full fp32 logits [B,S,128100] read every step; " if args.full_logits else
                                 "loss-only step as in main.py:67: full fp32 logits [B,S,128100] filled on access (not read here); ")
                                + "CE + head backward on labelled rows",
-                       "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted"},
+                       "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted",
+                       **({"model.training_graphs": True} if args.training_graphs else {})},
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
             "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
             # data parallel: ranks RCCL's collectives ran over (0 = no reducer / not the nccl backend) and where in backward
@@ -441,11 +449,13 @@ def run_downstream(args):
                                         graphs=not args.no_inference_graphs)))
 
 
-def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed):
+def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=False):
     """The product's `main.train_one_epoch` (reference signature, main.py:24-96) over `steps` synthetic batches: host-side
     tokenisation stand-in + `mask_tokens` on the CPU generator + host-to-device copies + forward + loss logging + backward +
     clip + Adam -- the headline times the step body on resident inputs, this is the loop a user runs.  delayed =
-    `args.delayed_loss_check` (the loss of step i is read when step i+1 calls instead of before its own backward)."""
+    `args.delayed_loss_check` (the loss of step i is read when step i+1 calls instead of before its own backward); graphs =
+    `model.training_graphs` (forward and backward replayed as hipGraphs: the host needs ~2 ms to issue the backward once it
+    has read the loss, instead of ~12)."""
     import contextlib
     import io
     import types
@@ -470,7 +480,8 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed):
 
     g = torch.Generator().manual_seed(21)
     batches = []
-    for _ in range(steps + 2):
+    n_warm = 5 if graphs else 2  # (graphs: the labelled-row capacities of the timed batches should have been captured)
+    for _ in range(steps + n_warm):
         tlen = torch.randint(Lt // 8, Lt + 1, (B,), generator=g)
         tlen[-1] = Lt
         ids = torch.randint(5, 127000, (B, Lt), generator=g) * (torch.arange(Lt)[None] < tlen[:, None])
@@ -479,20 +490,25 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed):
         batches.append(dict(video=torch.randn(B, T, F, generator=g).half().float(), video_len=vlen, text=list(ids)))
 
     class Loader(list):
-        dataset = list(range(B * (steps + 2)))
+        dataset = list(range(B * (steps + n_warm)))
 
     largs = types.SimpleNamespace(max_tokens=Lt, mlm_prob=0.15, print_freq=10 ** 9, epochs=1, lr=3e-5, schedule="",
                                   fraction_warmup_steps=0.1, delayed_loss_check=delayed)
     model.train()
-    with contextlib.redirect_stdout(io.StringIO()):
-        P_main.train_one_epoch(model, Tok(), Loader(batches[:2]), opt, model.device, 0, largs, 0.1)  # warm-up
-        torch.cuda.synchronize()
-        t0 = time.time()
-        P_main.train_one_epoch(model, Tok(), Loader(batches[2:]), opt, model.device, 0, largs, 0.1)
-        torch.cuda.synchronize()
-    dt = time.time() - t0
+    model.training_graphs = bool(graphs)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            P_main.train_one_epoch(model, Tok(), Loader(batches[:n_warm]), opt, model.device, 0, largs, 0.1)  # warm-up
+            torch.cuda.synchronize()
+            t0 = time.time()
+            P_main.train_one_epoch(model, Tok(), Loader(batches[n_warm:]), opt, model.device, 0, largs, 0.1)
+            torch.cuda.synchronize()
+        dt = time.time() - t0
+    finally:
+        model.training_graphs = False
+        model.__dict__.pop("_train_graphs", None)
     return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "args.delayed_loss_check": bool(delayed)}
+            "args.delayed_loss_check": bool(delayed), "model.training_graphs": bool(graphs)}
 
 
 def spawn_ranks(n: int) -> int:

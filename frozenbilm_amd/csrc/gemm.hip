@@ -494,11 +494,21 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   // fourth round of full tiles (222 us) loses to three rounds plus small tiles (208 us).  FBL_GEMM8_SKEW=0 disables.
   static const int skew_mode = FBL_ENV_INT("FBL_GEMM8_SKEW", 50);
   static const int gemm8_on = FBL_ENV_INT("FBL_GEMM8", 3);
+  // FBL_GEMM_PREF224=1 (measurement builds): where the skewed launch applies and 224-row tiles cover the problem in less
+  // (rounds x tile rows) than 256-row tiles, ONE plain launch of 224x256 tiles instead
+  static const int pref224 = FBL_ENV_INT("FBL_GEMM_PREF224", 0);
+  bool plain_224 = false;
   bool skewed_single_launch = false;
   if (big && splitk_ws_floats >= 0 && skew_mode > 0 && gemm8_on > 0 && gemm8_eligible(g)) {
     const long total = (long)((N + 255) / 256) * ((M + 255) / 256);
     const long rem = total % 256;
-    if (total > 256 && rem >= 96 && rem <= 192) {
+    if (pref224 && total > 256 && rem >= 96 && rem <= 192) {
+      const int n_cu = device_cu_count();
+      const long t224 = (long)((N + 255) / 256) * ((M + 223) / 224);
+      const long c256 = ((total + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+      plain_224 = c224 * 100 < c256 * 97;
+    }
+    if (total > 256 && rem >= 96 && rem <= 192 && !plain_224) {
       skewed_single_launch = true;
       g.skew_first = (int)rem;
       g.skew_blocks = 256;
@@ -506,7 +516,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       g.skew_ticks = (int)(tile_us * 100.0 / 5.0 * 0.01 * skew_mode);  // four groups, (1..4) x skew_mode/5 % of a tile late
     }
   }
-  if (big && splitk_ws_floats >= 0 && !skewed_single_launch && !tail) {  // (negative values mark the two halves of an already split launch)
+  if (big && splitk_ws_floats >= 0 && !skewed_single_launch && !tail && !plain_224) {  // (negative values mark the two halves of an already split launch)
     // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
     // round would be mostly empty, give the big tiles only as many M rows as fill whole rounds and run the remaining
     // rows with the 128x128 configuration (2 workgroups/CU, 1/4 of the work per tile) right behind.

@@ -360,31 +360,39 @@ __device__ __forceinline__ float fold16(const float* ws, int nblk, int ncols, in
   }
   return s;
 }
-// A block owns 64 consecutive columns of ws[nblk][3H]: 16 lanes x float4 read 256 contiguous bytes of a partial row, the
-// 16 lane groups stride over the rows (full cache lines: the 16-column variant above reads 64-byte pieces), then a
-// fixed-order fold of the 16 groups through LDS -- deterministic.
+// A block owns 32 consecutive columns of ws[nblk][3H]: 8 lanes x float4 read one 128-byte line of a partial row, the 32
+// lane groups stride over the rows with eight independent loads in flight each (the fold is a latency chain, not a
+// bandwidth problem: the 14 MB of partials have just been written and sit in the Infinity Cache; with 16 groups x 4 loads
+// it took 11 us per LayerNorm, 54 times a step), then a fixed-order fold of the groups -- in-wave butterflies over the 8
+// groups of a wave, the 4 waves through LDS -- deterministic.
 __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta,
                                                           float* dysum) {
-  __shared__ f32x4 red[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int col = blockIdx.x * 64 + tx * 4;
+  __shared__ f32x4 red[4][8];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 32 + tx * 4;
   const int ncols = 3 * H;  // (H % 64 == 0: a block never straddles two of the three sums, nor the end)
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (col < ncols) {
     const float* p = ws + col;
     int b = ty;
-    for (; b + 48 < nblk; b += 64) {  // four independent loads in flight
-      const f32x4 a0 = *(const f32x4*)(p + (long)b * ncols), a1 = *(const f32x4*)(p + (long)(b + 16) * ncols);
-      const f32x4 a2 = *(const f32x4*)(p + (long)(b + 32) * ncols), a3 = *(const f32x4*)(p + (long)(b + 48) * ncols);
-      s += (a0 + a1) + (a2 + a3);
-    }
-    for (; b < nblk; b += 16) s += *(const f32x4*)(p + (long)b * ncols);
-  }
-  red[ty][tx] = s;
-  __syncthreads();
-  if (ty == 0 && col < ncols) {
+    for (; b + 224 < nblk; b += 256) {
+      f32x4 v[8];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) s += red[k][tx];
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(p + (long)(b + 32 * u) * ncols);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; b < nblk; b += 32) s += *(const f32x4*)(p + (long)b * ncols);
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], o, 64);
+  }
+  if (lane < 8) red[wave][lane] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && col < ncols) {
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
     float* dst = col < H ? dgamma : (col < 2 * H ? dbeta : dysum);
     if (dst) {
       float* q = dst + (col % H);
@@ -869,7 +877,7 @@ extern "C" int fbl_ln_bwd(const float* dout, const int32_t* rowmask, const float
   }
   FBL_CHECK_LAUNCH();
   if (dgamma || dbeta || dysum) {
-    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, nblk, H,
                        dgamma, dbeta, dysum);
     FBL_CHECK_LAUNCH();
   }
