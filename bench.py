@@ -99,6 +99,9 @@ def main():
                     help="do not re-measure roofline.traffic (two short rocprofv3 --pmc child runs of this script); the newest "
                          "committed profiles/*_traffic.json is reported instead")
     ap.add_argument("--prewarm", type=int, default=PREWARM_STEPS, help=argparse.SUPPRESS)
+    ap.add_argument("--packed-rows", action="store_true",
+                    help="time the step with model.packed_rows = True (NOT the headline: reported under its own metric name; "
+                         "for profiling the packed step)")
     ap.add_argument("--training-graphs", action="store_true",
                     help="time the step with model.training_graphs = True (reported in config; for profiling the replayed step)")
     ap.add_argument("--no-inference-graphs", action="store_true",
@@ -111,6 +114,8 @@ def main():
         return run_downstream(args)
     if args.training_graphs:  # (a replayed step issues no launches the roofline instrumentation could bracket)
         args.no_roofline = args.no_extras = True
+    if args.packed_rows:
+        args.no_extras = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -142,6 +147,7 @@ def main():
     model.to(dev)
     model.train(not args.eval_forward)
     model.training_graphs = bool(args.training_graphs)
+    model.packed_rows = bool(args.packed_rows)
     eng = model.engine()
     opt = FusedAdam(model, lr=3e-5, betas=(0.9, 0.95))
     # FBL_FORCE_REDUCER=1 exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
@@ -292,6 +298,37 @@ def main():
                                   "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
                                   "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
                                           "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step as under `host`"}
+        # the same step with model.packed_rows: the batch is ragged (text 32..256 tokens, 1..10 frames) and every GEMM,
+        # LayerNorm and adapter of the headline step also processes the padding rows behind each sample's last token, as
+        # the reference does.  Packed, those rows do not exist.  A separately named object: its fraction
+        # counts EXECUTED FLOPs only (per sample: the op list of executed_flops_per_sample at that sample's own length)
+        # and earns nothing against the padded op list; the headline `value` stays reference-shaped.
+        model.packed_rows = True
+        try:
+            d = timed(lambda: step(False), n_x)
+            with torch.no_grad():
+                model.eval()
+                pk = model(**batch)._run.pk
+                with model.weights_frozen():
+                    d_f = timed(fwd_only, n_x)
+                model.train()
+        finally:
+            model.packed_rows = False
+        if pk is not None:
+            plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
+            ex_p = [executed_flops_per_sample(S=s, rows_labelled=rows_lab, layers=args.layers) for s in plen]
+            exf_p, exb_p = sum(e[0] for e in ex_p), sum(e[1] for e in ex_p)
+            extras["packed_rows"] = {
+                "value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                "rows": int(pk.n), "grid_rows": B * S,
+                "executed_tflops_per_step": (exf_p + exb_p) / 1e12,
+                "executed_frac_of_peak": (exf_p + exb_p) / d / 1e12 / PEAK_BF16_TFLOPS,
+                "eval_forward": {"value": world * B / d_f, "unit": "samples/s", "ms_per_step": d_f * 1e3,
+                                 "executed_frac_of_peak": exf_p / d_f / 1e12 / PEAK_BF16_TFLOPS},
+                "note": "model.packed_rows = True (opt-in extension, frozenbilm_amd.engine.Packing): the same batch, same "
+                        "loss and gradients (tests/test_gpu_model.py::test_packed_rows_*), without the padding rows behind "
+                        "each sample's last token; NOT the headline: the reference computes those rows and the headline "
+                        "counts them"}
         if world == 1 and full_cfg:
             # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
             # and with the opt-in one-step-delayed loss check
@@ -314,13 +351,18 @@ def main():
             on = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=True)
             off = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False)
             on["eager_launches"] = {"value": off["value"], "ms_per_step": off["ms_per_step"]}
+            pkd = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False, packed=True)
+            on["packed_rows"] = {"value": pkd["value"], "ms_per_step": pkd["ms_per_step"],
+                                 "note": "model.packed_rows = True (eager launches): the same loop without the padding rows "
+                                         "behind each sample's last token"}
             extras[key] = on
 
     if rank == 0:
         full = args.layers == 24 and B == 32 and Lt == 256
         out = {
             "metric": ("video-text samples/sec (MLM fwd+bwd) DeBERTa-XL+adapters" if not args.eval_forward
-                       else "video-text samples/sec (MLM eval forward) DeBERTa-XL+adapters") + ("" if full else " [REDUCED CONFIG]"),
+                       else "video-text samples/sec (MLM eval forward) DeBERTa-XL+adapters") + ("" if full else " [REDUCED CONFIG]")
+                      + (" [PACKED ROWS: not the reference-shaped headline]" if args.packed_rows else ""),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -331,7 +373,8 @@ def main():
                                 "loss-only step as in main.py:67: full fp32 logits [B,S,128100] filled on access (not read here); ")
                                + "CE + head backward on labelled rows",
                        "dead_layer23_encoder_pass": "skipped (output unused, SURVEY fact 6); FLOPs still counted",
-                       **({"model.training_graphs": True} if args.training_graphs else {})},
+                       **({"model.training_graphs": True} if args.training_graphs else {}),
+                       **({"model.packed_rows": True} if args.packed_rows else {})},
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
             "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
             # data parallel: ranks RCCL's collectives ran over (0 = no reducer / not the nccl backend) and where in backward
@@ -347,11 +390,12 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_downstream(model, cfg, workload, steps, warmup, layers=24, graphs=True):
+def measure_downstream(model, cfg, workload, steps, warmup, layers=24, graphs=True, packed=False):
     """BASELINE configs[3] / configs[4] on one GPU: the product's videoqa.evaluate / mc.evaluate loops (reference
     signatures) over synthetic batches resident in HBM; a step = one batch through the loop body (forward, [MASK]-row
     head, softmax, top-k / candidate arg-max).  `model` is put into eval mode and gets the workload's answer table
-    (set_answer_embeddings: n_ans = 1000 / 2).  graphs: `args.inference_graphs` of the loops (one hipGraph per batch shape)."""
+    (set_answer_embeddings: n_ans = 1000 / 2).  graphs: `args.inference_graphs` of the loops (one hipGraph per batch shape);
+    packed: `model.packed_rows` (the ragged batch without its padding rows; takes precedence over the graphs)."""
     import types
 
     from frozenbilm_amd import mc as P_mc
@@ -366,6 +410,7 @@ def measure_downstream(model, cfg, workload, steps, warmup, layers=24, graphs=Tr
     a2tok = a2tok * (torch.arange(5)[None] < torch.randint(1, 6, (n_ans, 1), generator=g))
     model.set_answer_embeddings(a2tok.to(dev))
     model.inference_graphs = False
+    model.packed_rows = bool(packed)
     MASK, B, T, F = 128000, (32 if vqa else 8), 10, 1024
     Lt = 256 if vqa else 502
     C = 1 if vqa else 4
@@ -420,6 +465,7 @@ def measure_downstream(model, cfg, workload, steps, warmup, layers=24, graphs=Tr
     tf = fwd_f * B * C * steps / dt / 1e12
     n_graphs = len(model.__dict__.get("_graph_cache", {}))
     model.inference_graphs = False
+    model.packed_rows = False
     model.__dict__.pop("_graph_cache", None)
     return {"metric": ("zero-shot open-ended VideoQA eval samples/sec (videoqa.evaluate, n_ans=1000)" if vqa else
                        "multiple-choice VideoQA eval questions/sec (mc.evaluate, 4 candidates, S=512)"),

@@ -32,6 +32,8 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     klen = getattr(run, "klen", None)
     border = getattr(run, "border", None)
     scale = 1.0 / math.sqrt(64 * 3)
+    pk_ = getattr(run, "pk", None)
+    row0 = pk_.row0 if pk_ is not None else None  # packed-row layout of q / k / v / dO and of the dQ / dK / dV outputs
 
     # One launch prepares the backward: K^T, Q^T (head-major), PK^T, PQ^T and D_i = dO_i . O_i.  (Folding D into kernel A
     # was measured: +43 us there for the O tiles on its critical path; five separate small launches: 65 us in situ.)
@@ -40,7 +42,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
-    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2)
+    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0)
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
@@ -51,7 +53,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     lin = 0 if rv is None else (eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30)
     lin_a = min(lin, span2 // 2) if eng.cfg.position_buckets > 0 else 0  # affine addressing of kernel A: identity buckets only
     L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
-                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a)
+                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
     G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
@@ -59,9 +61,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
         G1T.fill_(float("nan"))
         G2T.fill_(float("nan"))
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
-                            lin=lin, border=border)
+                            lin=lin, border=border, row0=row0)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
-                            rcnt=rcnt, lin=lin, border=border)
+                            rcnt=rcnt, lin=lin, border=border, row0=row0)
     del dS, dST
     state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen)
     if defer_pos:

@@ -61,11 +61,13 @@ struct PrepArgs {
   bf16* QT; bf16* KT; bf16* PQT; bf16* PKT; float* Dv;
   int B, S, Sp, nh, span2;
   int n_tr, n_tab;  // blocks of one K / Q transpose, of one table transpose
+  const int32_t* row0;  // [B+1] packed-row layout of q / k / dO / O (see attn_fwd.hip) or null; the outputs keep [B, S(p)]
 };
 
-// vt[h*sh + b*sb + d*sd + s] = v[b*S+s, h*64+d] (s < S), 0 for S <= s < Sp: one (64-position tile, head, sample)
+// vt[h*sh + b*sb + d*sd + s] = v[rb+s, h*64+d] (s < S), 0 for S <= s < Sp: one (64-position tile, head, sample); rb = first
+// row of the sample (b*S in the padded layout), S = number of its rows that exist
 __device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* v, long ldv, bf16* vt, int S, int Sp, long sh,
-                                                    long sb, long sd, int s0, int h, int b) {
+                                                    long sb, long sd, int s0, int h, int b, long rb) {
   const int t = threadIdx.x;
   {
     const int row = t >> 2, c0 = (t & 3) * 2;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* 
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (s < S) x = *(const uint4*)(v + ((long)b * S + s) * ldv + h * 64 + (c0 + c) * 8);
+      if (s < S) x = *(const uint4*)(v + (rb + s) * ldv + h * 64 + (c0 + c) * 8);
       uint32_t* d = tile + row * 33 + (c0 + c) * 4;
       d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
     }
@@ -103,8 +105,10 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
     if (isq) id -= a.n_tr;
     const int nst = a.Sp / 64;
     const int st = id % nst, h = (id / nst) % a.nh, b = id / (nst * a.nh);
-    head_transpose_tile(tile, isq ? a.q : a.k, a.ldq, isq ? a.QT : a.KT, a.S, a.Sp, 64l * a.B * a.Sp, a.Sp, (long)a.B * a.Sp,
-                        st * 64, h, b);
+    const long rb = a.row0 ? (long)a.row0[b] : (long)b * a.S;
+    const int lim = a.row0 ? min(a.row0[b + 1] - a.row0[b], a.S) : a.S;  // (rows beyond it read as zero, like S <= s < Sp)
+    head_transpose_tile(tile, isq ? a.q : a.k, a.ldq, isq ? a.QT : a.KT, lim, a.Sp, 64l * a.B * a.Sp, a.Sp, (long)a.B * a.Sp,
+                        st * 64, h, b, rb);
     return;
   }
   id -= 2 * a.n_tr;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
     const int nst = a.span2 / 64;
     const int st = id % nst, h = id / nst;
     head_transpose_tile(tile, isq ? a.pq : a.pk, a.ldp, isq ? a.PQT : a.PKT, a.span2, a.span2, 64l * a.span2,
-                        (long)a.nh * 64 * a.span2, a.span2, st * 64, h, 0);
+                        (long)a.nh * 64 * a.span2, a.span2, st * 64, h, 0, 0);
     return;
   }
   id -= 2 * a.n_tab;
@@ -124,22 +128,26 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
     const int c = (int)(gid & 7);
     const long total = (long)a.B * a.S * a.nh;
     const bool live = idx < total;
-    const long row = live ? idx / a.nh : 0;
+    const long row = live ? idx / a.nh : 0;  // position of the padded [B, S] grid
     const int h = live ? (int)(idx % a.nh) : 0;
+    const int bb = (int)(row / a.S), ss = (int)(row % a.S);
+    long arow = row;  // its activation row (packed layout: positions without one get D = 0)
+    bool has = live;
+    if (a.row0 && live) {
+      has = ss < a.row0[bb + 1] - a.row0[bb];
+      arow = (long)a.row0[bb] + ss;
+    }
     float s = 0.f;
-    if (live) {
-      const bf16x8 x = *(const bf16x8*)(a.dO + row * a.ldo + h * 64 + c * 8);
-      const bf16x8 y = *(const bf16x8*)(a.O + row * a.ldo + h * 64 + c * 8);
+    if (has) {
+      const bf16x8 x = *(const bf16x8*)(a.dO + arow * a.ldo + h * 64 + c * 8);
+      const bf16x8 y = *(const bf16x8*)(a.O + arow * a.ldo + h * 64 + c * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (live && c == 0) {
-      const int bb = (int)(row / a.S), ss = (int)(row % a.S);
-      a.Dv[((long)bb * a.nh + h) * a.S + ss] = s;
-    }
+    if (live && c == 0) a.Dv[((long)bb * a.nh + h) * a.S + ss] = s;
   }
 }
 
@@ -157,6 +165,7 @@ struct BwdAArgs {
   int lin;  // |d| < lin: idx(d) = idx(0) + d (identity buckets); 0 = unknown
   const uint64_t* seed_dev;  // optional device word added to seed (fbl_seed); last: the offsets of the fields above are what the
                              // register allocation of this kernel was tuned with (any field in front of them costs spills)
+  const int32_t* row0;       // [B+1] packed-row layout of q / k / v / dO / dV (PACKED kernels; see attn_fwd.hip) or null
 };
 
 // LDS: Q, dO tiles (per iteration) and this workgroup's K tile 3 x 8 KiB, T1 / T2 2 x 13 KiB (reused as the dS / dS^T
@@ -183,7 +192,7 @@ struct ATileRegs {
 // DEVSEED: the dropout seed gets the device word added (launch graphs).  Two instantiations on purpose: this kernel sits at
 // its register cap, and the scalar load + add in front of the key derivation costs the common (DEVSEED = false) launch
 // 24 more bytes of spills per lane and 14 % of its time (120 -> 136 us, same box) if it shares one body with it.
-template <bool DEVSEED>
+template <bool DEVSEED, bool PACKED = false>
 __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,7 +202,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   const WgCoord wc = wg_coord(Sp / 64, a.nh, a.B, a.border);
   const int j0 = wc.x * 64, h = wc.h, b = wc.b;
   const int j = j0 + w * 16 + c;  // this lane's key
-  const int jc = min(j, S - 1);
+  // first activation row of this sample and the number of its rows that exist (PACKED: ragged batches without padding rows)
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;
+  const int jc = min(j, lim - 1);
   const int tq = Sp - 1;  // idx[i - j + tq]
 
   int16_t* idx = (int16_t*)(smem + A_IDX);
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
 
   bf16x8 vf[2];  // V fragments of this lane's key (the K fragments are read from the K tile in LDS where they are used)
   {
-    const long off = ((long)b * S + jc) * a.ldq + h * 64 + g * 8;
+    const long off = (rb + jc) * a.ldq + h * 64 + g * 8;
     vf[0] = *(const bf16x8*)(a.v + off);
     vf[1] = *(const bf16x8*)(a.v + off + 32);
   }
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       *(bf16x8*)(smem + A_KS + sb + t * 4096) =
-          *(const bf16x8*)(a.k + ((long)b * S + min(j0 + srow + t * 32, S - 1)) * a.ldq + h * 64 + sch * 8);
+          *(const bf16x8*)(a.k + (rb + min(j0 + srow + t * 32, lim - 1)) * a.ldq + h * 64 + sch * 8);
     if (tid < 64) kms[tid] = (j0 + tid < S && a.mask[(long)b * S + min(j0 + tid, S - 1)] != 0) ? 1.f : 0.f;
     // T1 / T2 slots that no row tile of a pair covers are still gathered by padding rows / columns (whose P is forced
     // to 0 through lse = +inf or a -inf T2 row): they must hold finite-or--inf values, never NaN bit patterns
@@ -245,14 +257,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
     const int i0 = it * 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int i = min(i0 + srow + t * 32, S - 1);
-      R.q[t] = *(const bf16x8*)(a.q + ((long)b * S + i) * a.ldq + h * 64 + sch * 8);
-      R.d[t] = *(const bf16x8*)(a.dO + ((long)b * S + i) * a.ldo + h * 64 + sch * 8);
+      const int i = min(i0 + srow + t * 32, lim - 1);
+      R.q[t] = *(const bf16x8*)(a.q + (rb + i) * a.ldq + h * 64 + sch * 8);
+      R.d[t] = *(const bf16x8*)(a.dO + (rb + i) * a.ldo + h * 64 + sch * 8);
     }
     R.lse = INFINITY; R.D = 0.f;  // lse = +inf (padding and masked queries: the forward stores +inf) -> P = 0
     if (tid < 64) {
       const int i = i0 + tid;
-      if (i < S) {
+      if (i < lim) {
         const long o = ((long)b * a.nh + h) * S + i;
         R.lse = a.lse[o] * LOG2E;
         R.D = a.Dv[o];
@@ -446,8 +458,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
     __syncthreads();
   }
 
-  if (j < S) {
-    bf16* op = a.dV + ((long)b * S + j) * a.lddv + h * 64 + g * 4;
+  if (j < lim) {
+    bf16* op = a.dV + (rb + j) * a.lddv + h * 64 + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
@@ -467,6 +479,7 @@ struct ShearArgs {
   int B, S, Sp, nh, span2, Wg;            // Wg: columns of the G tile (multiple of 32)
   int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
   int lin;                                // |delta| < lin: idx(delta) is injective (identity buckets) -> plain stores
+  const int32_t* row0;                    // [B+1] packed-row layout of `out` (PACKED kernels; see attn_fwd.hip) or null
 };
 constexpr int C_IDX = 0;           // int16[1024]: relative-index table padded to the tile grid
 constexpr int C_G = C_IDX + 2048;  // [32][Wg + 8] bf16
@@ -480,7 +493,7 @@ constexpr int C_G = C_IDX + 2048;  // [32][Wg + 8] bf16
 //  * the table GEMM walks only the index range the valid columns [0, klen) can reach, and G^T leaves through the
 //    matrix cores: D = G_frag . I puts 4 consecutive rows of one table index in a lane (an exact transpose of the bf16
 //    values), so there is no column-wise LDS read-out.
-template <bool NEG>
+template <bool NEG, bool PACKED = false>
 __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -497,13 +510,15 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + bx) * a.rcnt) * 32;
   const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int kl = a.klen ? min(a.klen[b], S) : S;
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;                  // first output row of this sample
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;          // output rows that exist
   if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
     // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
     // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
     if ((bx & 1) && (r0 - 32 < kl))
       if (!(FBL_ATTN_DBGBITS & 64)) for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
-    if (row < S) {
-      bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
+    if (row < lim) {
+      bf16* op = a.out + (rb + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = (bf16x4){0, 0, 0, 0};
     }
@@ -643,8 +658,8 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     if (kk + 2 < nks) load_pt(kk + 2, pa);
     if (kk + 1 < nks) table_step(kk + 1, pb);
   }
-  if (row < S) {
-    bf16* op = a.out + ((long)b * S + row) * a.ldout + h * 64 + g * 4;
+  if (row < lim) {
+    bf16* op = a.out + (rb + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
@@ -669,24 +684,32 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
                                       const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                                       const int32_t* mask, const int32_t* klen, const int32_t* border, const float* lse, const float* Dv, float scale, float p_drop,
                                       uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp,
-                                      int nh, int span2, int lin_span, void* stream) {
+                                      int nh, int span2, int lin_span, const int32_t* row0, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldo % 8) || (ldp % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
   BwdAArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ldq, (const bf16*)dO, ldo, (const bf16*)pk, (const bf16*)pq, ldp, relidx, mask, klen, border, lse, Dv, scale, p_drop, seed, (bf16*)dV, lddv,
-             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span, seed_dev};
+             (bf16*)dS, (bf16*)dST, B, S, Sp, nh, span2, lin_span, seed_dev, row0};
   attn_debug_init();
   const int smem_bytes = a_total(Sp);
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem_bytes;
   }
   const dim3 grid((unsigned)(Sp / 64) * nh * B);
-  if (seed_dev && p_drop > 0.f)
+  const bool devseed = seed_dev && p_drop > 0.f;
+  if (row0 && devseed)
+    hipLaunchKernelGGL((attn_bwd_ds_kernel<true, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else if (row0)
+    hipLaunchKernelGGL((attn_bwd_ds_kernel<false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else if (devseed)
     hipLaunchKernelGGL(attn_bwd_ds_kernel<true>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_ds_kernel<false>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
@@ -697,7 +720,7 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
                                          int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen,
                                          const int32_t* border, void* out, int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
-                                         int Sp, int nh, int span2, void* stream) {
+                                         int Sp, int nh, int span2, const int32_t* row0, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
@@ -706,8 +729,9 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   if (Wg > span2) Wg = span2;
   Wg = (Wg + 31) / 32 * 32;
   if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, border, (bf16*)out, ldout, (bf16*)GT,
-              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span};
+              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span, row0};
   attn_debug_init();
   const int smem_bytes = C_G + 32 * (Wg + 8) * 2;
   static int attr_bytes = 0;
@@ -716,10 +740,18 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
     hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e1 != hipSuccess) return (int)e1;
     if (e2 != hipSuccess) return (int)e2;
+    e1 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    e2 = hipFuncSetAttribute((const void*)attn_bwd_shear_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
     attr_bytes = smem_bytes;
   }
   dim3 grid((unsigned)(Sp / 32) * nh * B);
-  if (neg)
+  if (neg && row0)
+    hipLaunchKernelGGL((attn_bwd_shear_kernel<true, true>), grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
+  else if (row0)
+    hipLaunchKernelGGL((attn_bwd_shear_kernel<false, true>), grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
+  else if (neg)
     hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
@@ -729,12 +761,12 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
 
 extern "C" int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp,
                                  const void* dO, const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT,
-                                 float* Dv, int B, int S, int Sp, int nh, int span2, void* stream) {
+                                 float* Dv, int B, int S, int Sp, int nh, int span2, const int32_t* row0, void* stream) {
   if (S < 1 || Sp < S || Sp % 64 || span2 <= 0 || span2 % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldp % 8) || (ldo % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
   PrepArgs a{(const bf16*)q, (const bf16*)k, ldq, (const bf16*)pq, (const bf16*)pk, ldp, (const bf16*)dO, (const bf16*)O, ldo,
-             (bf16*)QT, (bf16*)KT, (bf16*)PQT, (bf16*)PKT, Dv, B, S, Sp, nh, span2, (Sp / 64) * nh * B, (span2 / 64) * nh};
+             (bf16*)QT, (bf16*)KT, (bf16*)PQT, (bf16*)PKT, Dv, B, S, Sp, nh, span2, (Sp / 64) * nh * B, (span2 / 64) * nh, row0};
   const long n_dot = ((long)B * S * nh * 8 + 255) / 256;
   const long grid = 2l * a.n_tr + 2l * a.n_tab + n_dot;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);

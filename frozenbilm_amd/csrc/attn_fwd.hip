@@ -37,6 +37,8 @@ struct AttnArgs {
   int B, S, Sp, nh, span2;
   int lin;  // |d| < lin: idx(d) = idx(0) + d (identity buckets); 0 = unknown
   int dbg;  // ablation switches (FBL_ATTN_DBG of debug builds; compiled out of the product library)
+  const int32_t* row0;  // [B+1] packed-row layout (PACKED kernels): sample b owns activation rows [row0[b], row0[b+1]) =
+                        // its positions 0 .. row0[b+1]-row0[b]-1; null = the padded [B, S] grid (row b*S + s)
 };
 #ifdef FBL_DEBUG_SWITCHES
 #define ATTN_DBG(bit) (a.dbg & (bit))
@@ -67,7 +69,9 @@ struct TileRegs {  // one key tile in flight: 4 x 16 B per thread
   float km;
 };
 
-template <int OCC, bool PF>
+// PACKED: q / k / v / ctx rows follow AttnArgs::row0 (ragged batches without their padding rows); mask and lse keep the
+// padded [B, S] indexing.  A separate instantiation: the padded kernel's code is unchanged.
+template <int OCC, bool PF, bool PACKED = false>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,6 +90,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
 
   const int kl = a.klen ? min(a.klen[b], S) : S;
   const int nkt = (i0 < kl) ? (kl + 63) / 64 : 0;  // masked key tiles contribute exactly 0; a fully masked query tile outputs 0
+  // first activation row of this sample and the number of its rows that exist (kl <= lim: the engine keeps every valid row)
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;
   if (nkt > 0) load_idx_padded(idx, a.relidx, S, Sp, tid, 256);
 
   // (the Q tile lives in LDS: B operands of Q.K^T and of the T1 row tiles are read from it where they are used)
@@ -117,9 +124,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = srow + t * 32;
-      const int j = min(j0 + row, S - 1);
-      R.k[t] = *(const bf16x8*)(a.k + ((long)b * S + j) * a.ldk + h * 64 + sch * 8);
-      R.v[t] = *(const bf16x8*)(a.v + ((long)b * S + j) * a.ldv + h * 64 + sch * 8);
+      const int j = min(j0 + row, lim - 1);
+      R.k[t] = *(const bf16x8*)(a.k + (rb + j) * a.ldk + h * 64 + sch * 8);
+      R.v[t] = *(const bf16x8*)(a.v + (rb + j) * a.ldv + h * 64 + sch * 8);
     }
     R.km = 0.f;
     if (tid < 64) {
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = srow + t * 32;
-      *(bf16x8*)(smem + SM_QS + sb + t * 4096) = *(const bf16x8*)(a.q + ((long)b * S + min(i0 + row, S - 1)) * a.ldq + h * 64 + sch * 8);
+      *(bf16x8*)(smem + SM_QS + sb + t * 4096) = *(const bf16x8*)(a.q + (rb + min(i0 + row, lim - 1)) * a.ldq + h * 64 + sch * 8);
     }
     __syncthreads();  // index table and Q tile visible
   }
@@ -331,12 +338,14 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
 
   const float inv_l = (qvalid && l_run > 0.f) ? 1.f / l_run : 0.f;
   if (i < S) {
-    bf16* op = a.ctx + ((long)b * S + i) * a.ldo + h * 64 + g * 4;
+    if (i < lim) {
+      bf16* op = a.ctx + (rb + i) * a.ldo + h * 64 + g * 4;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 v = o[dt] * inv_l;
-      if (inv_l == 0.f) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // masked query rows are exactly zero (their lane may hold garbage)
-      *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 v = o[dt] * inv_l;
+        if (inv_l == 0.f) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // masked query rows are exactly zero (their lane may hold garbage)
+        *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      }
     }
     if (g == 0 && a.lse)
       a.lse[((long)b * a.nh + h) * S + i] = (qvalid && l_run > 0.f) ? m_run * a.scale + __logf(l_run) : INFINITY;
@@ -397,12 +406,13 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
                                    const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                                    const int32_t* border, float scale, float p_drop, uint64_t seed,
                                    const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
-                                   int lin_span, void* stream) {
+                                   int lin_span, const int32_t* row0, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldp % 8) || (ldo % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;  // idx(0) +- (lin_span - 1 + 79) must stay inside the table
+  if (row0 && !klen) return FBL_ERR_ARG;  // the packed layout is defined by the samples' lengths
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, seed_dev, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, seed_dev, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0, row0};
   static const int dbg = FBL_ENV_INT("FBL_ATTN_DBG", 0);
   a.dbg = dbg;
   attn_debug_init();
@@ -412,11 +422,16 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem_bytes;
   }
   dim3 grid((unsigned)((S + 63) / 64) * nh * B);
-  hipLaunchKernelGGL((attn_fwd_kernel<3, false>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  if (row0)
+    hipLaunchKernelGGL((attn_fwd_kernel<3, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<3, false>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
+ABI_VERSION = 5  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -51,14 +51,14 @@ SIGNATURES = {
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
     "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l,
-                                 _vp, _i, _i, _i, _i, _i, _i, _vp]),
+                                 _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
-    "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+                                    _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
-                                       _vp]),
+                                       _vp, _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
@@ -493,8 +493,17 @@ def head_transpose(v, vt, B, S, Sp, nh, head_major=False):
     _chk(load().fbl_head_transpose(_p(v), ldv, _p(vt), B, S, Sp, nh, sh, sb, sd, _stream()), "fbl_head_transpose")
 
 
+def _row0(row0, B, klen):
+    """packed-row layout argument of the attention entry points: int32 [B+1] row offsets (needs klen) or None"""
+    if row0 is None:
+        return None
+    _req(row0, torch.int32, "row0")
+    assert row0.is_contiguous() and row0.numel() == B + 1 and klen is not None
+    return _p(row0)
+
+
 def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0, klen=None,
-                    border=None, lin=0):
+                    border=None, lin=0, row0=None):
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (pk, "pk"), (pq, "pq"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
@@ -503,7 +512,7 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
                                     _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _seed_dev(), _p(ctx), ldo,
-                                    _p(lse), B, S, Sp, nh, span2, int(lin), _stream()), "fbl_disent_attn_fwd")
+                                    _p(lse), B, S, Sp, nh, span2, int(lin), _row0(row0, B, klen), _stream()), "fbl_disent_attn_fwd")
 
 
 def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
@@ -517,7 +526,7 @@ def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
                                       _p(probs), B, S, nh, _stream()), "fbl_disent_attn_probs")
 
 
-def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2):
+def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=None):
     """K^T, Q^T (head-major), PK^T, PQ^T and D = rowdot(dO, O) in one launch (see fbl.h)"""
     ldq, ldp, ldo = _rows2d(q, "q"), _rows2d(pq, "pq"), _rows2d(dO, "dO")
     assert _rows2d(k, "k") == ldq and _rows2d(pk, "pk") == ldp and _rows2d(O, "O") == ldo
@@ -525,7 +534,7 @@ def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2
         _req(t, torch.bfloat16, "transposed output")
         assert t.is_contiguous()
     _chk(load().fbl_attn_bwd_prep(_p(q), _p(k), ldq, _p(pq), _p(pk), ldp, _p(dO), _p(O), ldo, _p(QT), _p(KT), _p(PQT), _p(PKT),
-                                  _p(Dv), B, S, Sp, nh, span2, _stream()), "fbl_attn_bwd_prep")
+                                  _p(Dv), B, S, Sp, nh, span2, _row0(row0, B, True), _stream()), "fbl_attn_bwd_prep")
 
 
 def attn_rowdot(dO, O, out, B, S, nh):
@@ -535,23 +544,24 @@ def attn_rowdot(dO, O, out, B, S, nh):
 
 
 def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, span2,
-                       p_drop=0.0, seed=0, klen=None, border=None, lin=0):
+                       p_drop=0.0, seed=0, klen=None, border=None, lin=0, row0=None):
     ldq = _rows2d(q, "q")
     assert _rows2d(k, "k") == ldq and _rows2d(v, "v") == ldq
     ldo, ldp, lddv = _rows2d(dO, "dO"), _rows2d(pk, "pk"), _rows2d(dV, "dV")
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_bwd_ds(_p(q), _p(k), _p(v), ldq, _p(dO), ldo, _p(pk), _p(pq), ldp,
                                        _p(relidx), _p(mask), _p(klen), _p(border), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed), _seed_dev(),
-                                       _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, int(lin), _stream()),
+                                       _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, int(lin), _row0(row0, B, klen), _stream()),
          "fbl_disent_attn_bwd_ds")
 
 
 def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None,
-                          rmin=0, rcnt=None, lin=0, border=None):
+                          rmin=0, rcnt=None, lin=0, border=None, row0=None):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
     _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(border), _p(out), ldout,
-                                          _p(GT), rmin, span2 if rcnt is None else rcnt, int(lin), B, S, Sp, nh, span2, _stream()),
+                                          _p(GT), rmin, span2 if rcnt is None else rcnt, int(lin), B, S, Sp, nh, span2,
+                                          _row0(row0, B, klen), _stream()),
          "fbl_disent_attn_bwd_shear")
 
 

@@ -225,6 +225,12 @@ class DebertaV2ForMaskedLM(nn.Module):
         self._engine = None
         self.inference_graphs = False  # opt-in: replay the `logit_rows` inference forward as one hipGraph (_graph_forward)
         self.training_graphs = False  # opt-in: the MLM training step as two replayed hipGraphs (train_graph.py)
+        # opt-in: ragged batches run without the padding rows behind each sample's last used position (engine.Packing) whenever
+        # the call's outputs live on selected rows (labels / logit_rows given).  Rows that exist get the same values as on the
+        # padded grid; `logits` / `hidden_states` read as zero at the dropped positions (the reference computes values there
+        # that nothing on this path reads), training-mode dropout draws a different -- equally distributed -- mask stream, and
+        # the launch graphs (shape-static) are not used while it is on.
+        self.packed_rows = False
         self._weights_frozen = 0  # nesting depth of weights_frozen(): inference forwards may reuse the packed operands
         self._reducer = None  # parallel.GradReducer attached to this model (survives engine rebuilds)
         self.step_seed = 0  # advanced every training forward; keys the counter-based dropout
@@ -451,13 +457,14 @@ class DebertaV2ForMaskedLM(nn.Module):
                 raise NotImplementedError("inputs_embeds is not on the FrozenBiLM hot path")
             raise ValueError("You have to specify either input_ids or inputs_embeds")
         eng = self.engine()
-        if (self.inference_graphs and logit_rows is not None and labels is None and not output_hidden_states
+        if (self.inference_graphs and not self.packed_rows and logit_rows is not None and labels is None and not output_hidden_states
                 and not output_attentions and not self.training and not torch.is_grad_enabled()):
             logits = self._graph_forward(eng, input_ids, attention_mask, video, video_mask, mlm, logit_rows)
             if logits is not None:
                 out = MaskedLMOutput(loss=None, logits=logits, hidden_states=None, attentions=None)
                 return out if return_dict is not False else (logits,)
-        if (self.training_graphs and self.training and labels is not None and not output_hidden_states and not output_attentions
+        if (self.training_graphs and not self.packed_rows and self.training and labels is not None and not output_hidden_states
+                and not output_attentions
                 and logit_rows is None and not (self.n_ans and not mlm) and torch.is_grad_enabled()):
             from ..train_graph import graphed_forward
 

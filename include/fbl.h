@@ -48,7 +48,7 @@ enum {
   FBL_AUX_ADAPTER_TAIL = 6    /* internal to fbl_adapter_up_resid_fwd; fbl_gemm_bf16_nt rejects it                */
 };
 
-/* Bumped whenever an exported argument list changes (4: this header); the ctypes binding refuses any other value. */
+/* Bumped whenever an exported argument list changes (5: this header); the ctypes binding refuses any other value. */
 int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
@@ -240,12 +240,18 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
  *   lin_span: |d| < lin_span => relidx[d+S-1] = relidx[S-1] + d (the identity buckets: position_buckets/2; 0 if
  *   unknown) -- tile pairs inside that band take index-table-free addressing;
  *   out ctx bf16 [B*S, ldo]; lse fp32 [B,nh,S] (log-sum-exp of the scaled scores, +inf for empty rows).
+ *   row0 int32 [B+1] (optional; needs klen): PACKED rows -- a ragged batch stored without its trailing padding rows.
+ *   Sample b then owns the q / k / v / ctx rows [row0[b], row0[b+1]), which are its positions 0 .. row0[b+1]-row0[b]-1
+ *   (>= klen[b]: every position up to the last valid one has a row; rows a sample does not have are neither read nor
+ *   written).  mask, lse and the scratch tensors of the backward keep their padded [B, S(p)] indexing.  The rows that
+ *   exist receive exactly the values of the padded layout.  The same argument on the three backward entry points below
+ *   (fbl_attn_bwd_prep: q / k / dO / O; fbl_disent_attn_bwd_ds: q / k / v / dO / dV; fbl_disent_attn_bwd_shear: out).
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
 int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                         const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                         const int32_t* mask, const int32_t* klen, const int32_t* border, float scale, float p_drop,
                         uint64_t seed, const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
-                        int lin_span, void* stream);
+                        int lin_span, const int32_t* row0, void* stream);
 
 /* The attention probabilities of fbl_disent_attn_fwd, materialised on request (output_attentions=True; never on the hot
  * path): probs[b, h, i, j] fp32 [B, nh, S, S] = exp(score[i,j] - lse[b,h,i]) with the lse the fused forward stored, exactly 0
@@ -278,17 +284,17 @@ int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B
  * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D). */
 int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp, const void* dO,
                       const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT, float* Dv, int B, int S, int Sp,
-                      int nh, int span2, void* stream);
+                      int nh, int span2, const int32_t* row0, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                            const int32_t* border, const float* lse, const float* Dv,
                            float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B,
-                           int S, int Sp, int nh, int span2, int lin_span, void* stream);
+                           int S, int Sp, int nh, int span2, int lin_span, const int32_t* row0, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
                               const void* PT, const int16_t* relidx, const int32_t* klen, const int32_t* border,
                               void* out, int64_t ldout,
                               void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
-                              int span2, void* stream);
+                              int span2, const int32_t* row0, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */

@@ -28,7 +28,7 @@ def _engine_run(m, mask):
     B, S = mask.shape
     run = Run(B=B, S=S, T=0, Lt=S, train=False, save=False, seed_base=0, p_hid=0.0, p_att=0.0, p_ad=0.0)
     run.mask = mask.to(DEV).to(torch.int32).contiguous().view(-1)
-    run.mask_i32 = run.mask
+    run.mask_i32 = run.rowmask = run.mask
     run.mask_f = run.mask.to(F32)
     pos1 = torch.arange(1, S + 1, device=DEV, dtype=torch.int32)
     run.klen = (run.mask.view(B, S) * pos1).amax(1).to(torch.int32).contiguous()

@@ -958,3 +958,141 @@ def test_inference_shortcuts_change_nothing():
         l2_general = m(**batch).loss.item()
         p.mul_(1.0 / 1.5)
     assert abs(general - ref_loss) < 1e-5 and abs(l2 - l2_general) < 1e-5 and abs(l2 - ref_loss) > 1e-6
+
+
+def _packed_vs_grid(cfg, P, batch, tol_logits, tol_grad):
+    """the same model with and without `packed_rows` on one ragged batch (eval mode: no dropout streams to differ)"""
+    m = build(cfg, P, train=False)
+    dev_batch = to_dev(batch)
+    B, Lt = batch["input_ids"].shape
+    S = cfg.max_feats + Lt
+    out_g = m(**dev_batch, output_hidden_states=True)
+    out_g.loss.backward()
+    grads_g = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+    logits_g = out_g.logits.detach().clone()
+    hid_g = [h.clone() for h in out_g.hidden_states]
+    m.zero_grad(set_to_none=True)
+    m.packed_rows = True
+    out_p = m(**dev_batch, output_hidden_states=True)
+    run = out_p._run
+    assert run.pk is not None and run.N == run.pk.n < B * S, "the batch was not packed"
+    out_p.loss.backward()
+    # rows that exist: every position up to the last valid / labelled one of its sample
+    exist = torch.zeros(B * S, dtype=torch.bool, device=DEV)
+    exist[run.pk.sel] = True
+    full_mask = torch.cat([dev_batch["video_mask"], dev_batch["attention_mask"]], 1).bool().view(-1)
+    assert bool((exist | ~full_mask).all()), "a valid position lost its row"
+    assert abs(out_p.loss.item() - out_g.loss.item()) < 1e-4 * max(1.0, abs(out_g.loss.item()))
+    lp = out_p.logits.detach().reshape(B * S, -1)
+    lg = logits_g.reshape(B * S, -1)
+    d_log = (lp[exist] - lg[exist]).abs().max().item()
+    assert d_log < tol_logits, d_log
+    assert float(lp[~exist].abs().max().item() if bool((~exist).any()) else 0.0) == 0.0  # dropped positions read as zero
+    for hp, hg in zip(out_p.hidden_states, hid_g):
+        hp, hg = hp.reshape(B * S, -1), hg.reshape(B * S, -1)
+        assert (hp[exist] - hg[exist]).abs().max().item() < tol_logits
+        assert float(hp[~exist].abs().max().item()) == 0.0
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            ref = grads_g[n].float()
+            worst = max(worst, (p.grad.float() - ref).norm().item() / max(ref.norm().item(), 1e-12))
+    assert worst < tol_grad, worst
+    print(f"packed vs grid: rows {run.N}/{B * S}, logits max-abs diff {d_log:.2e}, worst gradient Frobenius diff {worst:.2e}")
+    return m, run
+
+
+def test_packed_rows_equal_the_padded_grid_tiny():
+    """model.packed_rows: a ragged batch without its trailing padding rows gives the loss, the logits / hidden states at
+    every position that has a row and the gradients of the padded grid (tiny config: 3 layers incl. the convolution, the
+    enhanced mask decoder and the position-table gradients); positions without a row read as zero."""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=61, std=0.05, ln_jitter=0.1)
+    for B, Lt, seed in ((5, 90, 3), (2, 33, 4), (7, 130, 5)):
+        _packed_vs_grid(cfg, P, synth_batch(cfg, B=B, L=Lt, seed=seed), tol_logits=2e-2, tol_grad=3e-2)
+
+
+def test_packed_rows_against_the_oracle_and_on_selected_rows():
+    """the packed forward / backward against the fp32 CPU oracle (same bounds as the padded path), and the inference
+    forward on selected rows (logit_rows, the downstream loops) packed vs padded"""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=62, std=0.05, ln_jitter=0.1)
+    batch = synth_batch(cfg, B=6, L=101, seed=8)
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    ref = O.forward(P, cfg, **batch)
+    ref["loss"].backward()
+    m = build(cfg, P)
+    m.packed_rows = True
+    out = m(**to_dev(batch))
+    out.loss.backward()
+    assert out._run.pk is not None
+    assert abs(out.loss.item() - ref["loss"].item()) < 2e-2
+    sel = out._run.pk.sel.cpu()
+    lg = out.logits.detach().float().cpu().reshape(-1, ref["logits"].shape[-1])
+    assert (lg[sel] - ref["logits"].detach().reshape(lg.shape)[sel]).abs().max().item() < 5e-2
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            r = P[name].grad
+            fro = (p.grad.float().cpu() - r).norm().item() / max(r.norm().item(), 1e-9)
+            assert fro < (0.25 if "adapter.down" in name else 6e-2), (name, fro)
+    # [MASK]-row inference: rows given as indices into the padded grid, whatever the layout underneath
+    S = cfg.max_feats + 101
+    feed = {k: v for k, v in to_dev(batch).items() if k != "labels"}
+    rows = torch.tensor([b * S + cfg.max_feats + 1 for b in range(6)], device=DEV)
+    with torch.no_grad():
+        packed = m(**feed, logit_rows=rows).logits.clone()
+        m.packed_rows = False
+        grid = m(**feed, logit_rows=rows).logits
+    assert packed.shape == grid.shape and (packed - grid).abs().max().item() < 2e-2
+
+
+def test_packed_rows_training_step_is_reproducible_and_finite():
+    """training mode (dropout live, keyed by packed row): two models stepped from the same state draw the same masks and
+    agree bit for bit; losses and gradients are finite; the loss stays close to the padded run's (different mask stream)"""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=63, std=0.05, ln_jitter=0.1)
+    batch = to_dev(synth_batch(cfg, B=6, L=77, seed=9))
+    losses, grads = [], []
+    for packed in (True, True, False):
+        m = build(cfg, P, train=True)
+        m.packed_rows = packed
+        out = m(**batch)
+        out.loss.backward()
+        assert (out._run.pk is not None) == packed
+        losses.append(out.loss.item())
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).clone())
+        assert torch.isfinite(grads[-1]).all() and torch.isfinite(out.loss)
+    assert losses[0] == losses[1] and torch.equal(grads[0], grads[1])
+    assert abs(losses[0] - losses[2]) < 0.2  # same model, another dropout stream
+
+
+@pytest.mark.slow
+def test_packed_rows_equal_the_padded_grid_at_xlarge_dimensions():
+    """the same at the true xlarge dimensions (4 layers): the 8-phase GEMMs, 24 heads, 192-wide adapters"""
+    cfg = O.OracleConfig()
+    cfg.num_hidden_layers, cfg.vocab_size = 4, 4096
+    P = O.synth_params(cfg, seed=64, std=0.02, ln_jitter=0.1)
+    _packed_vs_grid(cfg, P, synth_batch(cfg, B=8, L=256, seed=11), tol_logits=3e-2, tol_grad=3e-2)
+
+
+def test_packed_rows_gradient_through_the_logits():
+    """a loss the caller builds on the returned logits (downstream fine-tuning style) next to the internal MLM loss: the
+    gradient handed in on the [B, S, V] grid reaches the packed rows"""
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=65, std=0.05, ln_jitter=0.1)
+    batch = to_dev(synth_batch(cfg, B=4, L=70, seed=13))
+    valid = torch.cat([batch["video_mask"], batch["attention_mask"]], 1).bool()
+    w = torch.randn(4, cfg.max_feats + 70, cfg.vocab_size, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    w = w * valid[..., None] * 1e-3
+    grads = []
+    for packed in (False, True):
+        m = build(cfg, P)
+        m.packed_rows = packed
+        out = m(**batch)
+        (out.loss + (out.logits * w).sum()).backward()
+        assert (out._run.pk is not None) == packed
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad})
+    for n in grads[0]:
+        ref = grads[0][n].float()
+        assert (grads[1][n].float() - ref).norm().item() <= 1e-4 * max(ref.norm().item(), 1e-9), n

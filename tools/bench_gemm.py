@@ -24,7 +24,11 @@ HOT = [  # (M, N, K, variant)
 ]
 EDGE = [(4100, 3500, 256, "f32+bf16"), (4100, 3584, 384, "gelugrad"), (8512, 6144, 256, "addf32"), (8512, 6144, 256, "mulbf16"),
         (8512, 6144, 256, "addbf16"), (8512, 6144, 256, "dgelu"), (8512, 6144, 256, "gelu")]
-shapes = {"hot": SQUARE + HOT, "square": SQUARE, "all": SQUARE + HOT + EDGE, "edge": EDGE}[args.set]
+# the step's large GEMMs at the row count of a packed ragged batch (model.packed_rows: 5322 of 8512 rows at the bench batch)
+PACKED = [(5834, 4608, 1536, "bf16"), (5322, 1728, 1536, "bf16"), (5322, 6144, 1536, "gelugrad"), (5322, 1728, 6144, "bf16"),
+          (5322, 6144, 1536, "mulbf16"), (5322, 1536, 6144, "addf32"), (5322, 1536, 4608, "addf32"), (5322, 1536, 1792, "bf16"),
+          (4100, 1536, 6144, "addf32"), (6900, 1536, 6144, "addf32"), (3000, 1536, 6144, "addf32")]
+shapes = {"hot": SQUARE + HOT, "square": SQUARE, "all": SQUARE + HOT + EDGE, "edge": EDGE, "packed": PACKED}[args.set]
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FBL_"))
 print(f"# {tag or 'default switches'}", flush=True)
 for M, N, K, var in shapes:
