@@ -338,7 +338,9 @@ def main():
                                          "reference_order": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False),
                                          "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True),
                                          "reference_order_graphed": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False,
-                                                                                       graphs=True)}
+                                                                                       graphs=True),
+                                         "delayed_loss_check_packed_rows": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l,
+                                                                                              True, packed=True)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -495,7 +497,7 @@ def run_downstream(args):
                                         graphs=not args.no_inference_graphs)))
 
 
-def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=False):
+def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=False, packed=False):
     """The product's `main.train_one_epoch` (reference signature, main.py:24-96) over `steps` synthetic batches: host-side
     tokenisation stand-in + `mask_tokens` on the CPU generator + host-to-device copies + forward + loss logging + backward +
     clip + Adam -- the headline times the step body on resident inputs, this is the loop a user runs.  delayed =
@@ -539,7 +541,7 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=Fals
         dataset = list(range(B * (steps + n_warm)))
 
     largs = types.SimpleNamespace(max_tokens=Lt, mlm_prob=0.15, print_freq=10 ** 9, epochs=1, lr=3e-5, schedule="",
-                                  fraction_warmup_steps=0.1, delayed_loss_check=delayed)
+                                  fraction_warmup_steps=0.1, delayed_loss_check=delayed, packed_rows=bool(packed))
     model.train()
     model.training_graphs = bool(graphs)
     try:
@@ -552,9 +554,10 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=Fals
         dt = time.time() - t0
     finally:
         model.training_graphs = False
+        model.packed_rows = False
         model.__dict__.pop("_train_graphs", None)
     return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "args.delayed_loss_check": bool(delayed), "model.training_graphs": bool(graphs)}
+            "args.delayed_loss_check": bool(delayed), "model.training_graphs": bool(graphs), "args.packed_rows": bool(packed)}
 
 
 def spawn_ranks(n: int) -> int:

@@ -31,6 +31,8 @@ def _prepare(batch_dict, tokenizer, device, args, step_seed=0):
 
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, args, max_norm):
     model.train()
+    if getattr(args, "packed_rows", False) and hasattr(model, "packed_rows"):
+        model.packed_rows = True  # opt-in: ragged batches without the padding rows behind each sample's last token
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
     log = LossLog(run, "mlm_loss", delayed=getattr(args, "delayed_loss_check", False))
     for i_batch, batch_dict in run:
@@ -45,6 +47,8 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
 @torch.no_grad()
 def evaluate(model, tokenizer, data_loader, device, args):
     model.eval()
+    if getattr(args, "packed_rows", False) and hasattr(model, "packed_rows"):
+        model.packed_rows = True
     run = EpochRunner(data_loader, args, "Val:")
     log = LossLog(run, "mlm_loss", stop_on_nonfinite=False, delayed=getattr(args, "delayed_loss_check", False))
     with frozen_weights(model):

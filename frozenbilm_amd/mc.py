@@ -80,6 +80,8 @@ def evaluate(model, tokenizer, data_loader, device, dataset_name, args, split="t
     model.eval()
     if getattr(args, "inference_graphs", False) and hasattr(model, "inference_graphs"):
         model.inference_graphs = True  # replay the per-batch forward as one hipGraph (fixed batch shapes pay off most)
+    if getattr(args, "packed_rows", False) and hasattr(model, "packed_rows"):
+        model.packed_rows = True  # ragged batches without the padding rows behind each sample's last token (takes precedence)
     run = EpochRunner(data_loader, args, f"{split}:")
     res = {}
     with frozen_weights(model):  # nothing writes to the parameters during an evaluation: packed operands are reused
