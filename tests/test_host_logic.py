@@ -180,3 +180,34 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
     assert launches[1][:2] == names(7)  # the deferred pair leads the next launch
     assert sorted(ready) == sorted(["head"] + [f"layer{li}" for li in range(nL)]) and len(ready) == nL + 1
     assert ready.index("layer7") > ready.index("layer5")  # final only with the second launch
+
+
+def test_packed_row_layout_of_a_ragged_batch():
+    """engine.Packing (model.packed_rows): every sample keeps the rows of its positions 0 .. last used position (valid token,
+    label, requested logit row; at least the video slots); the maps between the padded grid and the packed rows are
+    consistent; a batch without droppable rows is not packed."""
+    from frozenbilm_amd.engine import Engine
+
+    eng = types.SimpleNamespace(dev=torch.device("cpu"))
+    B, T, Lt = 4, 3, 9
+    S = T + Lt
+    mask = torch.zeros(B, S, dtype=torch.int32)
+    mask[0, :2] = 1; mask[0, T:T + 4] = 1           # 2 frames, 4 tokens: last valid position T+3
+    mask[1, :T] = 1; mask[1, T:] = 1                # full length
+    mask[2, :1] = 1; mask[2, T:T + 1] = 1           # 1 frame, 1 token
+    mask[3, :T] = 1                                 # no text at all: the video slots stay
+    labels = torch.full((B, S), -100, dtype=torch.long)
+    labels[0, T + 2] = 7
+    labels[2, T + 5] = 9                            # a label behind the last valid token keeps its row
+    pk = Engine._make_packing(eng, mask, labels.view(-1), None, B, S, T)
+    plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
+    assert plen == [T + 4, S, T + 6, T] and pk.n == sum(plen) and pk.row0[0] == 0
+    assert pk.sel.tolist() == [b * S + s for b in range(B) for s in range(plen[b])]
+    assert pk.pos.tolist() == [s for b in range(B) for s in range(plen[b])]
+    assert torch.equal(pk.inv[pk.sel], torch.arange(pk.n)) and int((pk.inv >= 0).sum()) == pk.n
+    # requested logit rows extend a sample as labels do
+    rows = torch.tensor([2 * S + T + 7])
+    pk2 = Engine._make_packing(eng, mask, None, rows, B, S, T)
+    assert (pk2.row0[1:] - pk2.row0[:-1]).tolist() == [T + 4, S, T + 8, T] and int(pk2.inv[rows[0]]) >= 0
+    # nothing to drop -> no packing
+    assert Engine._make_packing(eng, torch.ones(B, S, dtype=torch.int32), None, rows, B, S, T) is None
