@@ -1,7 +1,7 @@
 """One rank of the two-rank data-parallel check of the HIP engine (launched by tests/test_gpu_model.py).
 
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv[1] = output file (rank 0 writes it),
-    argv[2] = GradReducer.overlap mode (optional), argv[3] = "tiny" (default) or "xl4": the true xlarge dimensions
+    argv[2] = GradReducer.overlap mode (optional), argv[3] = "tiny" (default), "tiny+packed" (model.packed_rows) or "xl4": the true xlarge dimensions
     (H = 1536, 24 heads, I = 6144, 192-wide adapters) with 4 layers, adapter gradients leaving in groups of 4 so that the
     stage buckets become final out of order under a real collective.
 
@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    xl = len(sys.argv) > 3 and sys.argv[3] == "xl4"
+    config = sys.argv[3] if len(sys.argv) > 3 else "tiny"
+    xl = config == "xl4"
     if xl:
         os.environ["FBL_DW_GROUP"] = "4"  # read at engine construction: 4 adapters per gradient launch
     multi = torch.cuda.device_count() >= world
@@ -41,6 +42,8 @@ def main():
         cfg = _tiny_cfg()
     m = build(cfg, O.synth_params(cfg, seed=41, std=0.02 if xl else 0.05, ln_jitter=0.1))  # eval mode: dropout off, gradients on
     m.to(dev)
+    if config == "tiny+packed":  # model.packed_rows: every rank packs its own ragged shard (different row counts per rank)
+        m.packed_rows = True
     # small buckets: several collectives in flight during backward; argv[2] = where they are launched (GradReducer.overlap)
     red = GradReducer.attach(m, min_bucket_elems=1 << 10, overlap=sys.argv[2] if len(sys.argv) > 2 else None)
     per = 2
