@@ -652,8 +652,31 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, long l
     for (int k = 0; k < 4; ++k) S += (red_m[k] == -INFINITY) ? 0.f : red_s[k] * __expf(red_m[k] - M);
     const float lse = M + logf(S);
     row_lse[row] = lse;
-    atomicAdd(loss_sum_cnt, lse - x[lab]);
-    atomicAdd(loss_sum_cnt + 1, 1.0f);
+  }
+}
+// loss_sum_cnt[0] += sum over labelled rows of (lse - logit[label]), [1] += their count: ONE block, thread t takes rows
+// t, t + 256, ..., fixed-order fold -- the loss is reproducible bit for bit (atomic adds from the row blocks were not).
+__global__ __launch_bounds__(256) void ce_fold_kernel(const float* logits, long ldv, const int64_t* labels, int N,
+                                                      const float* row_lse, float* loss_sum_cnt) {
+  __shared__ float red_s[4], red_c[4];
+  float s = 0.f, c = 0.f;
+  for (int r = threadIdx.x; r < N; r += 256) {
+    const int64_t lab = labels[r];
+    if (lab >= 0) {
+      s += row_lse[r] - logits[(long)r * ldv + lab];
+      c += 1.f;
+    }
+  }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    red_s[threadIdx.x >> 6] = s;
+    red_c[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss_sum_cnt[0] += (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    loss_sum_cnt[1] += (red_c[0] + red_c[1]) + (red_c[2] + red_c[3]);
   }
 }
 __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const float* logits, long ldv, const int64_t* labels,
@@ -975,6 +998,9 @@ extern "C" int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* label
   if (N <= 0) return 0;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, (long)ldv, labels, N, V,
                      row_lse, loss_sum_cnt);
+  FBL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (long)ldv, labels, N, row_lse,
+                     loss_sum_cnt);
   FBL_CHECK_LAUNCH();
   return 0;
 }

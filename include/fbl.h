@@ -297,7 +297,8 @@ int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_
                               int span2, const int32_t* row0, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
- * loss_sum_cnt[0] += sum of row losses, [1] += count; row_lse [N] fp32 out.  ref: model/deberta.py:1483-1488. */
+ * loss_sum_cnt[0] += sum of row losses, [1] += count (a fixed-order fold: reproducible bit for bit); row_lse [N] fp32 out.
+ * ref: model/deberta.py:1483-1488. */
 int fbl_ce_fwd(const float* logits, int64_t ldv, const int64_t* labels, int N, int V, float* row_lse,
                float* loss_sum_cnt, void* stream);
 /* dlogits_bf16[r, :] = (softmax(logits[rows[r]]) - onehot) * gscale * (gscale_dev ? gscale_dev[0] : 1) / count,
