@@ -339,6 +339,8 @@ static inline bool big_tile_shape(int M, int N, int batch) {
   return batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
 }
 
+constexpr double FBL_R128_US_PER_KTILE = 0.86;  // 128-row 8-phase tile: time per K-tile of one workgroup (measured: [5322,1536,6144] 88 us)
+
 static int device_cu_count() {
   static int n_cu = 0;
   if (!n_cu) {
@@ -614,7 +616,28 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
       const int bm = attempt == 0 ? 224 : 256;
       g8.tiles_m = (M + bm - 1) / bm;
       g8.tiles_n = (N + 255) / 256;
-      const int rc8 = launch_gemm8(g8, act, aux_kind, attempt == 0, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
+      const int rc8 = launch_gemm8(g8, act, aux_kind, bm, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
+      if (rc8 != FBL_ERR_ARG) return rc8;
+    }
+  }
+  // 128-row 8-phase tiles for problems the tall tiles leave half the chip idle on (the N = 1536 dX GEMMs at the row counts
+  // of packed ragged batches / small batches: M = 5322 -> 21 x 6 = 126 tiles of 256 rows, 42 x 6 = 252 of 128 rows) and
+  // that would otherwise run on the 128x128 two-stage kernel.  Chosen by a two-line cost model from measured per-K-tile
+  // times (tools/bench_gemm.py --set packed): rounds x (K-tiles x us per K-tile + epilogue).  FBL_GEMM_R128 (measurement
+  // builds): 0 = never, 2 = whenever the kernel can take the launch.
+  static const int r128_mode = FBL_ENV_INT("FBL_GEMM_R128", 1);
+  if (!use_big && r128_mode > 0 && gemm8_mode > 0 && !accumulate && batch == 1 && splitk_ws_floats >= 0 && !tail && seg_n <= 0 &&
+      p_drop <= 0.f && M >= 1024 && N >= 1024 && N <= 8192 && gemm8_eligible(g)) {
+    const int n_cu = device_cu_count();
+    const long t128 = (long)((M + 127) / 128) * ((N + 255) / 256), tsm = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const double nk = K / 64.0;
+    const double us128 = (double)((t128 + n_cu - 1) / n_cu) * (nk * FBL_R128_US_PER_KTILE + 6.0);
+    const double ussm = (double)((tsm + 2 * n_cu - 1) / (2 * n_cu)) * (nk * 1.17 + 5.0);
+    if (r128_mode >= 2 || us128 < 0.95 * ussm) {
+      GemmArgs g8 = g;
+      g8.tiles_m = (M + 127) / 128;
+      g8.tiles_n = (N + 255) / 256;
+      const int rc8 = launch_gemm8(g8, act, aux_kind, 128, dim3(g8.tiles_m * g8.tiles_n, 1), (hipStream_t)stream);
       if (rc8 != FBL_ERR_ARG) return rc8;
     }
   }

@@ -55,10 +55,13 @@ constexpr int RING_BYTES = 8 * HT_BYTES;     // 128 KiB
 constexpr int SMEM8_BYTES = (8 * 64 * 68 * 4 > RING_BYTES) ? 8 * 64 * 68 * 4 : RING_BYTES;  // epilogue staging is larger
 
 // VAR bit 0: stagger the two wave rows by half a phase; bit 1: s_setprio around the MFMA cluster (experiment switches)
-// R224: 224-row tile (halves of 112 rows: the first wave row owns 64 rows of each half, the second one 48 = three 16-row
-// MFMA tiles) for the M = 8512, N = 1536 GEMMs of the step: 38 x 6 = 228 tiles instead of 204 that are 14 % bigger.
-template <int ACT, int AUX, int VAR, bool R224 = false>
+// RT = 1 (R224): 224-row tile (halves of 112 rows: the first wave row owns 64 rows of each half, the second one 48 = three
+// 16-row MFMA tiles) for the M = 8512, N = 1536 GEMMs of the step: 38 x 6 = 228 tiles instead of 204 that are 14 % bigger.
+// RT = 2 (R128): 128-row tile (halves of 64 rows, BOTH wave rows own 32 of each = two MFMA tiles) for row counts at which
+// neither of the tall tiles covers the chip (packed ragged batches, small batches: M = 5322, N = 1536 -> 252 tiles).
+template <int ACT, int AUX, int VAR, int RT = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
+  constexpr bool R224 = RT == 1, R128 = RT == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,7 +76,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const uint64_t wait = (uint64_t)k * (uint64_t)g.skew_ticks;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
-  constexpr int HROWS = R224 ? 112 : 128;  // rows of an A half-tile
+  constexpr int HROWS = R224 ? 112 : R128 ? 64 : 128;  // rows of an A half-tile
+  constexpr int WROWS = R128 ? 32 : 64;                // rows of a half-tile that one wave row owns (the first one)
+  constexpr int NRT = R128 ? 2 : 4;                    // its 16-row MFMA tiles
   const int m0 = tm * (2 * HROWS), n0 = tn * 256;
   const int nk = g.K / BK;  // even, >= 4
   const bool short_rows = R224 && wm == 1;  // this wave owns 3 (not 4) row tiles per half
@@ -88,8 +93,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int rr = (j * 8 + wave) * 8 + lrow;  // row inside the half-tile slot
-      // (224-row tiles: slot rows 112..127 are never read; their lanes re-request row 111 so that every wave issues
-      //  the same number of DMA instructions and one vmcnt count serves all)
+      // (224-row tiles: slot rows 112..127 are never read -- 128-row tiles: 64..127 --; their lanes re-request the last
+      //  row so that every wave issues the same number of DMA instructions and one vmcnt count serves all)
       const int am = min(m0 + h * HROWS + min(rr, HROWS - 1), g.M - 1);
       const int bn = min(n0 + h * 128 + rr, g.N - 1);
       a_off[h][j] = (uint32_t)(((long)am * g.lda + lchunk * 8) * 2);
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 
   // fragment read offsets inside a half-tile: row*128 + ((s*4 + lane>>4) ^ (row&7))*16; k-sub-step s=1 flips bit 6
   const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
-  const int a_rd0 = (wm * 64 + frow) * 128 + ((fg ^ fsw) * 16);
+  const int a_rd0 = (wm * WROWS + frow) * 128 + ((fg ^ fsw) * 16);
   const int a_rd1 = a_rd0 ^ 64;
   const int b_rd0 = (wn * 32 + frow) * 128 + ((fg ^ fsw) * 16);
   const int b_rd1 = b_rd0 ^ 64;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   auto read_a = [&](auto Hc, auto Bc) {
     constexpr int SLOT = (decltype(Bc)::value * 4 + (decltype(Hc)::value ? 3 : 0)) * HT_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // (the fourth row tile of a short wave reads slot rows it never uses: harmless)
+    for (int i = 0; i < NRT; ++i) {  // (the fourth row tile of a short wave reads slot rows it never uses: harmless)
       af[i][0] = *(const bf16x8*)(smem + SLOT + i * 2048 + a_rd0);
       af[i][1] = *(const bf16x8*)(smem + SLOT + i * 2048 + a_rd1);
     }
@@ -242,6 +247,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   if constexpr (R224) {
     if (short_rows) k_loop(IC<3>{});
     else k_loop(IC<4>{});
+  } else if constexpr (R128) {
+    k_loop(IC<2>{});
   } else {
     k_loop(IC<4>{});
   }
@@ -258,17 +265,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     return;
   }
   const int ec = (lane & 15) * 4;
-  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3, R224>(g, smem, wave, lane, acc, m0 + wm * 64, HROWS, n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31),
-                                    0, 0, short_rows ? 48 : 64);
+  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3, R224, NRT>(g, smem, wave, lane, acc, m0 + wm * WROWS, HROWS,
+                                                               n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31), 0, 0,
+                                                               R128 ? 32 : (short_rows ? 48 : 64));
 }
 
-template <int ACT, int AUX, bool R224>
+template <int ACT, int AUX, int RT>
 int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   static const int var = FBL_ENV_INT("FBL_GEMM8_VAR", 3);
 #define FBL_G8_LAUNCH(VAR_)                                                                                     \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
-    auto kfn = gemm8_kernel<ACT, AUX, VAR_, R224>;                                                              \
+    auto kfn = gemm8_kernel<ACT, AUX, VAR_, RT>;                                                                \
     if (!attr_set) {                                                                                            \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES); \
       if (e != hipSuccess) return (int)e;                                                                       \
@@ -277,7 +285,7 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL(kfn, grid, dim3(512), SMEM8_BYTES, stream, g);                                           \
   } while (0)
 #ifdef FBL_DEBUG_SWITCHES
-  if constexpr ((ACT == FBL_ACT_NONE || ACT == FBL_ACT_GELU_GRAD) && AUX == FBL_AUX_NONE && !R224) {  // experiment variants
+  if constexpr ((ACT == FBL_ACT_NONE || ACT == FBL_ACT_GELU_GRAD) && AUX == FBL_AUX_NONE && RT == 0) {  // experiment variants
     if (var == 0) FBL_G8_LAUNCH(0);
     else if (var == 1) FBL_G8_LAUNCH(1);
     else if (var == 2) FBL_G8_LAUNCH(2);
@@ -306,19 +314,25 @@ bool gemm8_eligible(const GemmArgs& g) {
   return true;
 }
 
-int launch_gemm8(const GemmArgs& g, int act, int aux_kind, bool rows224, dim3 grid, hipStream_t stream) {
-  if (rows224) {  // the N = 1536 GEMMs of the step: plain (one or two outputs) and residual-add epilogues
-    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, true>(g, grid, stream);
-    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, true>(g, grid, stream);
+// rows: 256, 224 or 128 (tile height)
+int launch_gemm8(const GemmArgs& g, int act, int aux_kind, int rows, dim3 grid, hipStream_t stream) {
+  if (rows == 224) {  // the N = 1536 GEMMs of the step: plain (one or two outputs) and residual-add epilogues
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, 1>(g, grid, stream);
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, 1>(g, grid, stream);
     return FBL_ERR_ARG;
   }
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, false>(g, grid, stream);
-  if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU, FBL_AUX_NONE, false>(g, grid, stream);
-  if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU_GRAD, FBL_AUX_NONE, false>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, false>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_BF16, false>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_BF16, false>(g, grid, stream);
-  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16, false>(g, grid, stream);
+  if (rows == 128) {  // the same GEMMs at row counts that leave the tall tiles' grids half empty
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, 2>(g, grid, stream);
+    if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, 2>(g, grid, stream);
+    return FBL_ERR_ARG;
+  }
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_NONE, FBL_AUX_NONE, 0>(g, grid, stream);
+  if (act == FBL_ACT_GELU && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU, FBL_AUX_NONE, 0>(g, grid, stream);
+  if (act == FBL_ACT_GELU_GRAD && aux_kind == FBL_AUX_NONE) return launch_variant<FBL_ACT_GELU_GRAD, FBL_AUX_NONE, 0>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_F32) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_F32, 0>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_ADD_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_ADD_BF16, 0>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_BF16, 0>(g, grid, stream);
+  if (act == FBL_ACT_NONE && aux_kind == FBL_AUX_MUL_DGELU_BF16) return launch_variant<FBL_ACT_NONE, FBL_AUX_MUL_DGELU_BF16, 0>(g, grid, stream);
   return FBL_ERR_ARG;
 }
 

@@ -241,7 +241,8 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmArgs& g, char* smem
 // DBG (measurement builds only): bit 0 = everything but the global stores (values kept alive), bit 1 = the stores of all
 // tile rows alias the first 256 rows of C (the output stays L2-resident: store issue without HBM write traffic)
 // SHORT48: slab_rows may be 48 (second wave row of the 224-row 8-phase tile): gets its own branch-free row loop.
-template <int ACT, int AUX, bool SPLITK, int MI, int DBG = 0, bool SHORT48 = false>
+// TPS: 16-row tiles per slab that carry results (4; 2 for the 128-row 8-phase tile, whose waves own 32 rows of each half).
+template <int ACT, int AUX, bool SPLITK, int MI, int DBG = 0, bool SHORT48 = false, int TPS = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int wave, int lane, f32x4 (&acc)[4][MI],
                                               int m_first, int m_slab_stride, int n4, int batch, int ks,
                                               int slab_rows = 64) {
@@ -275,7 +276,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
   //  accumulator indices stay compile-time constants -- a rolled loop would put the accumulator array into scratch memory)
   auto slab = [&](auto halfc) {
     constexpr int half = decltype(halfc)::value;
-    constexpr int cnt = (MI - half * 4 < 4) ? MI - half * 4 : 4;  // 16-row tiles in this slab
+    constexpr int cnt0 = (MI - half * 4 < 4) ? MI - half * 4 : 4;
+    constexpr int cnt = cnt0 < TPS ? cnt0 : TPS;  // 16-row tiles in this slab
     const int mslab = m_first + half * m_slab_stride;
     // The aux operand of the slab is requested BEFORE the accumulators make their LDS round trip: issued inside the
     // row loop, every iteration exposed a full global-load latency (32 dependent loads per wave on a 256x256 tile).
@@ -296,7 +298,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      if (half * 4 + mi < MI) {
+      if (half * 4 + mi < MI && mi < cnt) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           *(f32x4*)(stage + (mi * 16 + frow) * LDW + ni * 16 + fg * 4) = acc[ni][half * 4 + mi];
@@ -448,7 +450,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
 
 // 8-phase 256x256 kernel (gemm8.hip).  Returns 0 when launched, FBL_ERR_ARG for an epilogue combination it does not
 // instantiate (the caller then uses the 2-stage kernel).
-int launch_gemm8(const GemmArgs& g, int act, int aux_kind, bool rows224, dim3 grid, hipStream_t stream);
+int launch_gemm8(const GemmArgs& g, int act, int aux_kind, int rows, dim3 grid, hipStream_t stream);  // rows: 256 / 224 / 128
 bool gemm8_eligible(const GemmArgs& g);
 
 
