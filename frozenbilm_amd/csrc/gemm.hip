@@ -458,7 +458,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.kskip_len = kskip_len;
   g.kskip_steps = kskip_steps;
   g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_seed_dev = drop_seed_dev; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
-  g.skew_first = 0; g.skew_blocks = 0; g.skew_ticks = 0;
   g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
   g.r_t = nullptr; g.ld_r = 0; g.r_stats = nullptr; g.r_gamma = nullptr; g.r_beta = nullptr; g.r_rowmask = nullptr;
   if (tail) {
@@ -489,36 +488,20 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0 || tail) && (seg_n <= 0 || (seg_n & 255) == 0) &&
                    big_tile_shape(M, N, batch);
   // A multi-round problem of the 8-phase kernel whose partial last round still uses a good part of the chip (96..192 of 256
-  // CUs; the QKV projection: 648 tiles) runs as ONE launch with a start skew instead of "whole rounds + 128x128 remainder":
-  // the CUs the last round does not need start up to 0.4 tiles late, which costs no wall time and takes the CUs out of
-  // lockstep (measured [9024,4608,1536]: 146 -> 133 us).  With a nearly empty last round (FFN-up: 816 tiles, 48 left) the
-  // split stays better: an epilogue costs a CU 10-20 us of VALU / store time that nothing on that CU overlaps, so a
-  // fourth round of full tiles (222 us) loses to three rounds plus small tiles (208 us).  FBL_GEMM8_SKEW=0 disables.
-  static const int skew_mode = FBL_ENV_INT("FBL_GEMM8_SKEW", 50);
+  // CUs; the QKV projection [9024,4608,1536]: 648 tiles of 256 rows, 738 of 224) runs as ONE plain launch instead of "whole
+  // rounds + 128x128 remainder" (122 us as 224-row tiles; the split: 146).  With a nearly empty last round (FFN-up: 816
+  // tiles, 48 left) the split stays better: an epilogue costs a CU 10-20 us of VALU / store time that nothing on that CU
+  // overlaps, so a fourth round of full tiles (222 us) loses to three rounds plus small tiles (208 us).
+  // (Rounds 2-3 delayed part of the first round by a spin-wait on the real-time clock to take the CUs out of lockstep: worth
+  //  13 us on the 256-row launch, nothing on the 224-row one the problem takes now -- removed.)
   static const int gemm8_on = FBL_ENV_INT("FBL_GEMM8", 3);
-  // FBL_GEMM_PREF224=1 (measurement builds): where the skewed launch applies and 224-row tiles cover the problem in less
-  // (rounds x tile rows) than 256-row tiles, ONE plain launch of 224x256 tiles instead
-  static const int pref224 = FBL_ENV_INT("FBL_GEMM_PREF224", 0);
-  bool plain_224 = false;
-  bool skewed_single_launch = false;
-  if (big && splitk_ws_floats >= 0 && skew_mode > 0 && gemm8_on > 0 && gemm8_eligible(g)) {
+  bool single_launch = false;
+  if (big && splitk_ws_floats >= 0 && gemm8_on > 0 && gemm8_eligible(g)) {
     const long total = (long)((N + 255) / 256) * ((M + 255) / 256);
     const long rem = total % 256;
-    if (pref224 && total > 256 && rem >= 96 && rem <= 192) {
-      const int n_cu = device_cu_count();
-      const long t224 = (long)((N + 255) / 256) * ((M + 223) / 224);
-      const long c256 = ((total + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
-      plain_224 = c224 * 100 < c256 * 97;
-    }
-    if (total > 256 && rem >= 96 && rem <= 192 && !plain_224) {
-      skewed_single_launch = true;
-      g.skew_first = (int)rem;
-      g.skew_blocks = 256;
-      const double tile_us = (K / 64) * 1.4 + 10.0;  // measured: 1.4 us per K-tile + epilogue
-      g.skew_ticks = (int)(tile_us * 100.0 / 5.0 * 0.01 * skew_mode);  // four groups, (1..4) x skew_mode/5 % of a tile late
-    }
+    single_launch = total > 256 && rem >= 96 && rem <= 192;
   }
-  if (big && splitk_ws_floats >= 0 && !skewed_single_launch && !tail && !plain_224) {  // (negative values mark the two halves of an already split launch)
+  if (big && splitk_ws_floats >= 0 && !single_launch && !tail) {  // (negative values mark the two halves of an already split launch)
     // Wave quantisation: one 256x256 workgroup per CU, so a grid of T tiles costs ceil(T/CUs) rounds.  When the last
     // round would be mostly empty, give the big tiles only as many M rows as fill whole rounds and run the remaining
     // rows with the 128x128 configuration (2 workgroups/CU, 1/4 of the work per tile) right behind.

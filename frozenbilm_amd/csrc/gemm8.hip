@@ -69,13 +69,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
   tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
-  if (g.skew_ticks > 0 && (int)blockIdx.x >= g.skew_first && (int)blockIdx.x < g.skew_blocks) {
-    // first-round workgroups [skew_first, skew_blocks): four groups, 1..4 skew steps late
-    const int k = 1 + (((int)blockIdx.x - g.skew_first) * 4) / (g.skew_blocks - g.skew_first);
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    const uint64_t wait = (uint64_t)k * (uint64_t)g.skew_ticks;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
   constexpr int HROWS = R224 ? 112 : R128 ? 64 : 128;  // rows of an A half-tile
   constexpr int WROWS = R128 ? 32 : 64;                // rows of a half-tile that one wave row owns (the first one)
   constexpr int NRT = R128 ? 2 : 4;                    // its 16-row MFMA tiles

@@ -42,12 +42,6 @@ struct GemmArgs {
   float drop_inv_keep;
   long drop_ld;
   long drop_row0;  // row offset added to m in the dropout key (the rows of a split launch keep their global keys)
-  // 8-phase kernel only: start skew.  One workgroup fits a CU, so the first skew_blocks (= CU count) workgroups start
-  // together and every CU then runs its sequence of tiles in lockstep with all others -- main loops (MFMA) all at once,
-  // epilogues (HBM traffic) all at once.  The workgroups [skew_first, skew_blocks) of the first round -- as many as there
-  // are CUs the partial LAST round does not need, so the delay costs no wall time -- wait 1..4 x skew_ticks ticks of the
-  // 100 MHz real-time clock before they start: their CUs' epilogues then overlap the other CUs' main loops.
-  int skew_first, skew_blocks, skew_ticks;
   // Second output segment (fbl_dense_adapter_down_fwd): columns n >= seg_n are NOT part of C but the adapter bottleneck
   // z[m, n - seg_n] = dropout(relu(v)) (bf16, row stride seg_ld; dropout = drop_* keyed by m*seg_ld + n - seg_n), whatever
   // ACT / AUX the kernel was instantiated with.  seg_n == 0: off.  seg_n % 4 == 0.
