@@ -262,73 +262,75 @@ def main():
                                           "row, dead layer-23 pass) by the time; executed_* counts only what this forward ran "
                                           "(vocabulary GEMM on the labelled rows, 25 layer executions)"}
         extras["executed_tflops_per_step"] = (ex_f + ex_b) * B / 1e12
-        # host cost of one step where the GPU cannot hide it: the same launch sequence on a B=1 batch
-        small = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=77, device=dev)
-        keep = dict(batch)
-        batch.clear(); batch.update(small)
-        d = timed(lambda: step(False), n_x)
-        batch.clear(); batch.update(keep)
-        def host_issue_ms(n=4):
-            # what the HOST spends issuing one full-size step: the queue is empty when the step starts and nobody waits for
-            # the GPU afterwards (the label count at the start of forward finds its tiny kernel done at once)
-            tot = 0.0
-            for _ in range(n):
-                sync()
-                t = time.time()
-                step(False)
-                tot += time.time() - t
-            sync()
-            return tot / n * 1e3
-
-        extras["host"] = {"enqueue_ms_per_step": d * 1e3, "issue_ms_per_step": host_issue_ms(),
-                          "note": "enqueue_ms_per_step: wall time per step of the same launch sequence at B=1 (GPU work per launch "
-                                  "negligible: ~1450 dependent launches cost that much on the GPU side too); issue_ms_per_step: "
-                                  "host time to issue one full-size step into an empty queue, nobody waiting for the GPU"}
-        # the same step with model.training_graphs (forward and backward replayed as two hipGraphs; clip + Adam eager): GPU
-        # time per step, and the host cost where the GPU cannot hide it (B=1, as `host` above)
-        model.training_graphs = True
-        d = timed(lambda: step(False), n_x)
-        batch.clear(); batch.update(small)
-        dh = timed(lambda: step(False), n_x)
-        batch.clear(); batch.update(keep)
-        gi = host_issue_ms()
-        model.training_graphs = False
-        model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
-        extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                                  "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
-                                  "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
-                                          "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step as under `host`"}
-        # the same step with model.packed_rows: the batch is ragged (text 32..256 tokens, 1..10 frames) and every GEMM,
-        # LayerNorm and adapter of the headline step also processes the padding rows behind each sample's last token, as
-        # the reference does.  Packed, those rows do not exist.  A separately named object: its fraction
-        # counts EXECUTED FLOPs only (per sample: the op list of executed_flops_per_sample at that sample's own length)
-        # and earns nothing against the padded op list; the headline `value` stays reference-shaped.
-        model.packed_rows = True
-        try:
+        # single-GPU characterisations (host cost, launch graphs, packed rows): not repeated on every rank of a multi-GPU run
+        if world == 1:
+            # host cost of one step where the GPU cannot hide it: the same launch sequence on a B=1 batch
+            small = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=77, device=dev)
+            keep = dict(batch)
+            batch.clear(); batch.update(small)
             d = timed(lambda: step(False), n_x)
-            with torch.no_grad():
-                model.eval()
-                pk = model(**batch)._run.pk
-                with model.weights_frozen():
-                    d_f = timed(fwd_only, n_x)
-                model.train()
-        finally:
-            model.packed_rows = False
-        if pk is not None:
-            plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
-            ex_p = [executed_flops_per_sample(S=s, rows_labelled=rows_lab, layers=args.layers) for s in plen]
-            exf_p, exb_p = sum(e[0] for e in ex_p), sum(e[1] for e in ex_p)
-            extras["packed_rows"] = {
-                "value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                "rows": int(pk.n), "grid_rows": B * S,
-                "executed_tflops_per_step": (exf_p + exb_p) / 1e12,
-                "executed_frac_of_peak": (exf_p + exb_p) / d / 1e12 / PEAK_BF16_TFLOPS,
-                "eval_forward": {"value": world * B / d_f, "unit": "samples/s", "ms_per_step": d_f * 1e3,
-                                 "executed_frac_of_peak": exf_p / d_f / 1e12 / PEAK_BF16_TFLOPS},
-                "note": "model.packed_rows = True (opt-in extension, frozenbilm_amd.engine.Packing): the same batch, same "
-                        "loss and gradients (tests/test_gpu_model.py::test_packed_rows_*), without the padding rows behind "
-                        "each sample's last token; NOT the headline: the reference computes those rows and the headline "
-                        "counts them"}
+            batch.clear(); batch.update(keep)
+            def host_issue_ms(n=4):
+                # what the HOST spends issuing one full-size step: the queue is empty when the step starts and nobody waits for
+                # the GPU afterwards (the label count at the start of forward finds its tiny kernel done at once)
+                tot = 0.0
+                for _ in range(n):
+                    sync()
+                    t = time.time()
+                    step(False)
+                    tot += time.time() - t
+                sync()
+                return tot / n * 1e3
+
+            extras["host"] = {"enqueue_ms_per_step": d * 1e3, "issue_ms_per_step": host_issue_ms(),
+                              "note": "enqueue_ms_per_step: wall time per step of the same launch sequence at B=1 (GPU work per launch "
+                                      "negligible: ~1450 dependent launches cost that much on the GPU side too); issue_ms_per_step: "
+                                      "host time to issue one full-size step into an empty queue, nobody waiting for the GPU"}
+            # the same step with model.training_graphs (forward and backward replayed as two hipGraphs; clip + Adam eager): GPU
+            # time per step, and the host cost where the GPU cannot hide it (B=1, as `host` above)
+            model.training_graphs = True
+            d = timed(lambda: step(False), n_x)
+            batch.clear(); batch.update(small)
+            dh = timed(lambda: step(False), n_x)
+            batch.clear(); batch.update(keep)
+            gi = host_issue_ms()
+            model.training_graphs = False
+            model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
+            extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                      "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
+                                      "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
+                                              "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step as under `host`"}
+            # the same step with model.packed_rows: the batch is ragged (text 32..256 tokens, 1..10 frames) and every GEMM,
+            # LayerNorm and adapter of the headline step also processes the padding rows behind each sample's last token, as
+            # the reference does.  Packed, those rows do not exist.  A separately named object: its fraction
+            # counts EXECUTED FLOPs only (per sample: the op list of executed_flops_per_sample at that sample's own length)
+            # and earns nothing against the padded op list; the headline `value` stays reference-shaped.
+            model.packed_rows = True
+            try:
+                d = timed(lambda: step(False), n_x)
+                with torch.no_grad():
+                    model.eval()
+                    pk = model(**batch)._run.pk
+                    with model.weights_frozen():
+                        d_f = timed(fwd_only, n_x)
+                    model.train()
+            finally:
+                model.packed_rows = False
+            if pk is not None:
+                plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
+                ex_p = [executed_flops_per_sample(S=s, rows_labelled=rows_lab, layers=args.layers) for s in plen]
+                exf_p, exb_p = sum(e[0] for e in ex_p), sum(e[1] for e in ex_p)
+                extras["packed_rows"] = {
+                    "value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                    "rows": int(pk.n), "grid_rows": B * S,
+                    "executed_tflops_per_step": (exf_p + exb_p) / 1e12,
+                    "executed_frac_of_peak": (exf_p + exb_p) / d / 1e12 / PEAK_BF16_TFLOPS,
+                    "eval_forward": {"value": world * B / d_f, "unit": "samples/s", "ms_per_step": d_f * 1e3,
+                                     "executed_frac_of_peak": exf_p / d_f / 1e12 / PEAK_BF16_TFLOPS},
+                    "note": "model.packed_rows = True (opt-in extension, frozenbilm_amd.engine.Packing): the same batch, same "
+                            "loss and gradients (tests/test_gpu_model.py::test_packed_rows_*), without the padding rows behind "
+                            "each sample's last token; NOT the headline: the reference computes those rows and the headline "
+                            "counts them"}
         if world == 1 and full_cfg:
             # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
             # and with the opt-in one-step-delayed loss check
