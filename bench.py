@@ -208,6 +208,26 @@ def main():
     step_flops = (fwd_f if args.eval_forward else fwd_f + bwd_f) * B
     whole_step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
 
+    # box calibration (context for the reader, not a result): the pool's boxes differ -- the same tree measured 46.5-47.7 ms per
+    # step on most of them and 57.6 on one -- so the line carries what THIS box gives a fixed, well-known launch: the 8-phase
+    # GEMM at 4096^3 (1270-1370 TFLOP/s on a healthy box), right after the timed region.
+    box = None
+    if rank == 0:
+        ca = (torch.rand(4096, 4096, device=dev) * 2 - 1).to(torch.bfloat16)
+        cb = (torch.rand(4096, 4096, device=dev) * 2 - 1).to(torch.bfloat16)
+        co = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev)
+        for _ in range(5):
+            L.gemm(ca, cb, out_bf16=co)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            L.gemm(ca, cb, out_bf16=co)
+        e1.record()
+        torch.cuda.synchronize()
+        box = {"gemm_4096_tflops": 2.0 * 4096 ** 3 * 30 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
+               "note": "fbl_gemm_bf16_nt at 4096^3 on this box right after the timed region (1270-1370 on most boxes of the pool)"}
+        del ca, cb, co
+
     roofline = None
     if not args.no_roofline:
         # every rank replays the instrumented steps (they contain the gradient collectives); rank 0 reports its own
@@ -385,7 +405,7 @@ def main():
             # they are launched (parallel.GradReducer.overlap; FBL_DP_OVERLAP overrides the default for A/B runs)
             "rccl_ranks": red.rccl_ranks if red is not None else 0, "dp_overlap": red.overlap if red is not None else None,
             "algorithmic_tflops_per_step": step_flops / 1e12,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build, "box_calibration": box,
         }
         out.update(extras)
         print(json.dumps(out))
