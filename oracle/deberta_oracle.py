@@ -159,6 +159,40 @@ class adapter_gates:
         return False
 
 
+# Optional dropout-mask injection (test infrastructure): the reference trains with StableDropout / nn.Dropout live at six
+# sites per layer execution plus the embeddings, the convolution branch, the attention probabilities and the shared
+# relative-position table (model/deberta.py:142-240, 258, 332, 403, 779, 796, 1054; model/adapter.py:40-41).  Inside
+# ``with dropout_masks(provider)`` every one of those sites asks ``provider(kind, shape)`` -- in the REFERENCE's execution
+# order -- for a multiplicative mask (0 = dropped, 1/(1-p) = kept; None = no dropout at this site) and applies it, forward
+# and backward (XDropout.backward :185-190 multiplies the gradient by the same mask).  kinds: "emb" (:1054), "pos" (:779),
+# "att" (:796), "ad" (adapter bottleneck, adapter.py:41), "hid" (SelfOutput :258 / Output :332), "conv" (:403).
+# Two users: the golden G17 (masks drawn from a seeded generator exactly as the patched reference drew them: pins this
+# train-mode restatement) and the GPU train-mode parity tests (masks rebuilt from the HIP path's counter-based RNG).
+_DROP = None
+
+
+class dropout_masks:
+    def __init__(self, provider):
+        self.provider = provider
+
+    def __enter__(self):
+        global _DROP
+        self._prev, _DROP = _DROP, self.provider
+        return self
+
+    def __exit__(self, *exc):
+        global _DROP
+        _DROP = self._prev
+        return False
+
+
+def _drop(x: torch.Tensor, kind: str) -> torch.Tensor:
+    if _DROP is None:
+        return x
+    m = _DROP(kind, tuple(x.shape))
+    return x if m is None else x * m.to(x.dtype).view(x.shape)
+
+
 def adapter(x: torch.Tensor, P: Params, prefix: str, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
     """model/adapter.py:33-45 with default flags: x + up(drop(relu(down(x)))).
 
@@ -171,6 +205,7 @@ def adapter(x: torch.Tensor, P: Params, prefix: str, drop: Optional[torch.Tensor
         z = torch.relu(pre)
     if drop is not None:
         z = z * drop
+    z = _drop(z, "ad")  # model/adapter.py:40-41
     return x + _lin(z, P, prefix + ".up")
 
 
@@ -207,6 +242,7 @@ def disentangled_attention(
 
     span = cfg.att_span
     rel = torch.from_numpy(rel_pos).long()
+    rel_emb = _drop(rel_emb, "pos")  # :779 pos_dropout on the shared table, a fresh mask per layer execution
     pos_q = _rb(_split_heads(_lin(rel_emb[None], P, prefix + ".query_proj"), nh))  # :848-850 [nh,2span,d]
     pos_k = _rb(_split_heads(_lin(rel_emb[None], P, prefix + ".key_proj"), nh))  # :851-853
     pos_q = pos_q.repeat(B, 1, 1)
@@ -227,10 +263,12 @@ def disentangled_attention(
     rmask = ~(mask4d.bool())
     probs = torch.softmax(scores.masked_fill(rmask, float("-inf")), -1)
     probs = probs.masked_fill(rmask, 0.0)
+    probs_out = probs
+    probs = _drop(probs, "att")  # :796
     ctx = torch.bmm(_rb(probs.view(B * nh, S, S)), v)  # :797-802
     ctx = ctx.view(B, nh, S, d).permute(0, 2, 1, 3).reshape(B, S, H)  # :803-814
     if return_probs:
-        return ctx, probs
+        return ctx, probs_out
     return ctx
 
 
@@ -245,18 +283,20 @@ def layer(
     query_states: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """model/deberta.py:351-375 DebertaV2Layer (attention :271-297, SelfOutput :254-260,
-    Intermediate :310-313, Output :328-334), eval mode (dropout identity)."""
+    Intermediate :310-313, Output :328-334); dropout sites are identities unless masks are injected (dropout_masks)."""
     eps = cfg.layer_norm_eps
     ctx = disentangled_attention(hidden, mask4d, rel_pos, rel_emb, P, prefix + ".attention.self", cfg, query_states)
     resid = hidden if query_states is None else query_states  # :290-292
     o = _lin(ctx, P, prefix + ".attention.output.dense")
     if cfg.ds_factor_attn:
         o = adapter(o, P, prefix + ".attention.output.adapter")
+    o = _drop(o, "hid")  # :258
     a = _ln(o + resid, P, prefix + ".attention.output.LayerNorm", eps)
     h = gelu_erf(_lin(a, P, prefix + ".intermediate.dense"))
     f = _lin(h, P, prefix + ".output.dense")
     if cfg.ds_factor_ff:
         f = adapter(f, P, prefix + ".output.adapter")
+    f = _drop(f, "hid")  # :332
     return _ln(f + a, P, prefix + ".output.LayerNorm", eps)
 
 
@@ -267,6 +307,7 @@ def conv_layer(emb: torch.Tensor, resid: torch.Tensor, input_mask: torch.Tensor,
     c = F.conv1d(_rb(emb.permute(0, 2, 1).contiguous()), _rb(P[pre + ".conv.weight"]), P[pre + ".conv.bias"], padding=pad)
     c = c.permute(0, 2, 1).contiguous()
     c = c.masked_fill((1 - input_mask).bool()[..., None], 0.0)
+    c = _drop(c, "conv")  # :403
     out = _ln(resid + gelu_erf(c), P, pre + ".LayerNorm", cfg.layer_norm_eps)
     return out * input_mask[..., None].to(out.dtype)
 
@@ -281,6 +322,7 @@ def embeddings(input_ids, video, mask, P: Params, cfg: OracleConfig):
     pos = P[pre + ".position_embeddings.weight"][:S][None]  # :1020-1029 (position_ids = arange)
     x = _ln(x, P, pre + ".LayerNorm", cfg.layer_norm_eps)
     x = x * mask[..., None].to(x.dtype)  # :1045-1052
+    x = _drop(x, "emb")  # :1054
     return x, pos
 
 

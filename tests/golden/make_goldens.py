@@ -308,6 +308,73 @@ def g5_tiny_model(deberta):
     npz("G5b_tiny_textonly", logits=o2.logits)
 
 
+
+class _GenDropout(torch.nn.Module):
+    """nn.Dropout stand-in whose keep decisions come from a caller-owned generator (Adapter.dropout, model/adapter.py:21)"""
+
+    def __init__(self, p, gen):
+        super().__init__()
+        self.p, self.gen = p, gen
+
+    def forward(self, x):
+        if not self.training or self.p <= 0:
+            return x
+        keep = torch.empty_like(x).bernoulli_(1 - self.p, generator=self.gen)
+        return x * keep / (1 - self.p)
+
+
+def seeded_train_mode(deberta, adapter_mod, m, gen):
+    """Make every dropout site of the reference model draw from `gen`: StableDropout goes through the module-level
+    get_mask (model/deberta.py:151-168), the adapters own an nn.Dropout (model/adapter.py:21).  Returns an undo function."""
+    orig = deberta.get_mask
+
+    def get_mask(input, local_context):
+        assert not isinstance(local_context, deberta.DropoutContext)  # (context_stack is None on this path)
+        dropout = local_context
+        mask = None
+        if dropout > 0:
+            mask = (1 - torch.empty_like(input).bernoulli_(1 - dropout, generator=gen)).bool()
+        return mask, dropout
+
+    deberta.get_mask = get_mask
+    for mod in m.modules():
+        if isinstance(mod, adapter_mod.Adapter) and isinstance(mod.dropout, torch.nn.Dropout):
+            mod.dropout = _GenDropout(mod.dropout.p, gen)
+
+    def undo():
+        deberta.get_mask = orig
+
+    return undo
+
+
+def g17_train_mode(deberta, adapter_mod):
+    """The reference in train() mode (main.py:34) on the tiny model of G5 with every dropout decision drawn from ONE seeded
+    generator in the reference's own execution order: loss, logits, all trainable gradients.  The oracle, handed masks drawn
+    from an identically seeded generator in ITS execution order (oracle.dropout_masks), must reproduce them -- which pins the
+    place, the scale and the order of all dropout sites of the train-mode restatement (tests/test_oracle_golden.py)."""
+    from oracle.deberta_oracle import synth_params
+
+    cfg = _tiny_cfg()
+    P = synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    m = build_ref_model(deberta, cfg, P)
+    m.train()
+    gen = torch.Generator().manual_seed(1717)
+    undo = seeded_train_mode(deberta, adapter_mod, m, gen)
+    try:
+        batch = synth_batch(cfg, B=3, L=27, seed=55)
+        out = m(**batch)
+        out.loss.backward()
+    finally:
+        undo()
+    grads = {"grad." + n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    m.eval()
+    with torch.no_grad():
+        ev = m(**batch)
+    assert abs(ev.loss.item() - out.loss.item()) > 1e-4, "dropout was not live"
+    npz("G17_train_mode", gen_seed=np.array([1717]), p_hidden=np.array([0.1]), p_att=np.array([0.1]), p_adapter=np.array([0.1]),
+        logits=out.logits, loss=out.loss, **{"in." + k: v for k, v in batch.items()}, **grads)
+
+
 def g5c_attentions(deberta):
     """The tiny model of G5 (same weights, same batch) with output_attentions=True: the reference's `attentions` tuple -- one
     [B, heads, S, S] probability tensor per encoder layer (model/deberta.py:544-560) -- plus logits to tie the two calls."""
@@ -858,6 +925,7 @@ def main():
         "G6b": lambda: g6b_xlarge_backward(deberta),
         "G14": lambda: g14_g15_xlarge_downstream(deberta),  # writes G14 and G15
         "G16": lambda: g16_checkpoint(deberta, load_downstream()[2]),
+        "G17": lambda: g17_train_mode(deberta, adapter_mod),
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):

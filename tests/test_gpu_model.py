@@ -475,6 +475,76 @@ def test_gradients_vs_bf16_operand_oracle_tight(cfg, B, Lt):
     assert worst[0][0] < 2e-2, worst[:8]  # measured: 0.7 % worst, adapter.down included
 
 
+# ------------------------------------------------------------------------------------------------ round-5: train-mode parity
+def _gates_of(run, cfg):
+    g = []
+    for sv in run.layers:
+        if cfg.ds_factor_attn:
+            g.append((sv.z1[:, : cfg.hidden_size // cfg.ds_factor_attn] > 0).cpu())
+        if cfg.ds_factor_ff:
+            g.append((sv.z2[:, : cfg.hidden_size // cfg.ds_factor_ff] > 0).cpu())
+    return g
+
+
+@pytest.mark.parametrize("cfg,B,Lt", _tight_cfgs())
+def test_train_mode_parity_with_replayed_dropout_masks(cfg, B, Lt):
+    """The configuration the headline is timed in -- train(), dropout live at every reference site (model/deberta.py:142-240,
+    258, 332, 403, 779, 796, 1054; model/adapter.py:40-41; main.py:34) -- against the oracle.  The HIP kernels draw their masks
+    from a counter-based hash of (seed, element index); tests/dropout_replay.py restates that hash on the host, rebuilds the
+    masks of THIS forward from the per-site seeds the engine recorded and hands them to the oracle's dropout sites (whose
+    place / scale / order is pinned against the reference itself by golden G17).  Loss, logits and EVERY trainable gradient
+    must then agree like the eval-mode checks do: a dropout site at the wrong place, a wrong 1/(1-p) in one of the fused
+    epilogues (merged GEMM bottleneck, adapter tail, ln_fwd, attention kernels) or a site missing in backward fails here.
+    Checked for the eager step and for a `training_graphs` replay (per-site constants + device seed word)."""
+    from tests.dropout_replay import ReplayedMasks
+
+    tiny = cfg.hidden_size < 1024
+    P = O.synth_params(cfg, seed=43, std=0.05 if tiny else 0.02, ln_jitter=0.1)
+    batch = synth_batch(cfg, B=B, L=Lt, seed=9)
+    results = {}
+    for graphs in (False, True):
+        torch.manual_seed(777)  # (the model's mask stream mixes torch.initial_seed(): both models draw the same masks)
+        m = build(cfg, P, train=True)
+        m.training_graphs = graphs
+        out = m(**to_dev(batch))
+        run = out.__dict__["_run"]
+        if not graphs:
+            c = m.config
+            masks = ReplayedMasks(run, cfg, cfg.num_attention_heads, c.hidden_dropout_prob, c.attention_probs_dropout_prob,
+                                  m.adapter_dropout)
+            gates = _gates_of(run, cfg)
+            assert len(run.layers) == cfg.num_hidden_layers + 1 and masks.seed_emb != 0
+        else:
+            assert len(m.__dict__.get("_train_graphs", {})) == 1, "the step was not served by a captured graph"
+        out.loss.backward()
+        logits = out.logits.float().cpu()
+        results[graphs] = (out.loss.item(), logits, {n: p.grad.float().cpu().clone() for n, p in m.named_parameters() if p.requires_grad})
+        del m, out, run
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    with O.bf16_operands(), O.adapter_gates([g_.view(B, -1, g_.shape[-1]) for g_ in gates]), O.dropout_masks(masks):
+        ref = O.forward(P, cfg, **batch)
+        ref["loss"].backward()
+    assert masks.exhausted(), masks.asked
+    with torch.no_grad():
+        ev = O.forward(P, cfg, **batch)["loss"].item()
+    assert abs(ev - ref["loss"].item()) > 1e-3, "dropout made no difference: the comparison would prove nothing"
+    for graphs, (loss, logits, grads) in results.items():
+        tag = "graph replay" if graphs else "eager"
+        dl = abs(loss - ref["loss"].item())
+        de = (logits - ref["logits"]).abs().max().item()
+        worst = sorted(((round(_rel_fro(g_, P[n].grad), 4), n) for n, g_ in grads.items()), reverse=True)
+        print(f"train-mode parity [{tag}]: loss {loss:.5f} vs {ref['loss'].item():.5f} (eval-mode oracle {ev:.5f}), "
+              f"logits max-abs {de:.3e}, worst grads {worst[:4]}")
+        assert dl < 2e-2, (tag, dl)
+        assert de < 5e-2, (tag, de)
+        assert worst[0][0] < 2e-2, (tag, worst[:8])
+    # eager and replayed steps drew the same masks: identical results
+    assert results[False][0] == results[True][0]
+    for n in results[False][2]:
+        assert torch.equal(results[False][2][n], results[True][2][n]), n
+
+
 @pytest.mark.slow
 def test_xlarge_backward_golden(golden):
     """G6b: the reference's own backward at true xlarge dims (24 layers, H=1536, B=2, S=266): norms of all 298 trainable

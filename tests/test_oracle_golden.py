@@ -151,6 +151,47 @@ def test_g5_tiny_model_logits_loss_grads(golden):
     assert torch.equal(out2["logits"], out["logits"])
 
 
+def test_g17_train_mode_with_the_references_dropout_draws(golden):
+    """G17: the reference in train() mode with every dropout decision drawn from one seeded generator.  The oracle's dropout
+    sites (oracle.dropout_masks), fed masks from an identically seeded generator in the oracle's own execution order, must
+    reproduce the reference's loss, logits and every trainable gradient: that pins place, scale and ORDER of all dropout
+    sites of the train-mode restatement (model/deberta.py:142-240, 258, 332, 403, 779, 796, 1054; model/adapter.py:40-41)."""
+    g = golden("G17_train_mode")
+    cfg = _tiny_cfg()
+    P = O.synth_params(cfg, seed=5, std=0.05, ln_jitter=0.1)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k))
+    gen = torch.Generator().manual_seed(int(g["gen_seed"][0]))
+    p_of = {"emb": float(g["p_hidden"][0]), "pos": float(g["p_hidden"][0]), "hid": float(g["p_hidden"][0]),
+            "conv": float(g["p_hidden"][0]), "att": float(g["p_att"][0]), "ad": float(g["p_adapter"][0])}
+    kinds = []
+
+    def provider(kind, shape):
+        kinds.append(kind)
+        p = p_of[kind]
+        return torch.empty(shape).bernoulli_(1 - p, generator=gen) / (1 - p)
+
+    with O.dropout_masks(provider):
+        out = O.forward(P, cfg, return_hidden=True, **batch)  # (the reference runs -- and draws for -- the dead last-layer pass)
+    nexec = cfg.num_hidden_layers + 2
+    assert kinds.count("pos") == kinds.count("att") == nexec and kinds.count("ad") == kinds.count("hid") == 2 * nexec
+    assert kinds.count("emb") == kinds.count("conv") == 1 and kinds[0] == "emb"
+    assert abs(out["loss"].item() - g["loss"].item()) < 1e-5
+    assert maxabs(out["logits"], g["logits"]) < 5e-5
+    out["loss"].backward()
+    n = 0
+    for k, v in P.items():
+        if O.is_trainable(k):
+            ref = g["grad." + k]
+            assert maxabs(v.grad, ref) < 1e-4 * max(ref.abs().max().item(), 1e-3), k
+            n += 1
+    assert n == len([k for k in g if k.startswith("grad.")])
+    # without masks the same call is the eval-mode forward of G5
+    g5 = golden("G5_tiny_model")
+    assert maxabs(O.forward(P, cfg, **batch)["logits"], g5["logits"]) < 5e-5
+
+
 def test_g5b_text_only(golden):
     g5 = golden("G5_tiny_model")
     gb = golden("G5b_tiny_textonly")
