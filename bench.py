@@ -106,6 +106,13 @@ def main():
                     help="time the step with model.training_graphs = True (reported in config; for profiling the replayed step)")
     ap.add_argument("--no-inference-graphs", action="store_true",
                     help="downstream workloads: leave the loops' opt-in args.inference_graphs off (eager launches)")
+    ap.add_argument("--dp-overlap", default=None, choices=["attention_windows", "backward", "after"],
+                    help="where in backward the gradient collectives are launched (parallel.GradReducer.overlap; default: "
+                         "attention_windows) -- tools/scale_sweep.sh sweeps it")
+    ap.add_argument("--force-reducer", action="store_true", help="attach the GradReducer at N=1 too (bucket bookkeeping without collectives)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST HOOK, never used by the driver: every rank on cuda:0, collectives over gloo -- exercises the N > 1 "
+                         "code path on a one-GPU box; the line says rccl_ranks 0")
     ap.add_argument("--workload", default="mlm", choices=["mlm", "videoqa", "mc"],
                     help="mlm = BASELINE configs[1] (the headline); videoqa = configs[3] (zero-shot open-ended eval loop, "
                          "n_ans=1000); mc = configs[4] (4-way multiple choice, B=8, S=512)")
@@ -123,9 +130,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # FBL_BENCH_SHARE_GPU=1 (test hook, never set by the driver): every rank uses cuda:0 and the collectives go through gloo,
-    # so the N > 1 code path (rank spawning, reducer, max-over-ranks timing) can be exercised on a one-GPU box.
-    share = os.environ.get("FBL_BENCH_SHARE_GPU", "0") == "1"
+    # --share-gpu (test hook, never set by the driver): every rank uses cuda:0 and the collectives go through gloo, so the
+    # N > 1 code path (rank spawning, reducer, max-over-ranks timing) can be exercised on a one-GPU box.
+    share = bool(args.share_gpu)
     local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -150,8 +157,12 @@ def main():
     model.packed_rows = bool(args.packed_rows)
     eng = model.engine()
     opt = FusedAdam(model, lr=3e-5, betas=(0.9, 0.95))
-    # FBL_FORCE_REDUCER=1 exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
-    red = GradReducer.attach(model) if (world > 1 or os.environ.get("FBL_FORCE_REDUCER")) else None
+    # --force-reducer exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
+    red = GradReducer.attach(model, overlap=args.dp_overlap) if (world > 1 or args.force_reducer) else None
+    if world > 1 and not share and red.rccl_ranks != world:
+        # a multi-GPU line whose collectives did not run over RCCL on all N ranks is not a scaling measurement: refuse to print one
+        raise RuntimeError(f"--gpus {world}: the gradient exchange would run over {red.rccl_ranks} RCCL ranks "
+                           f"(backend {dist.get_backend()}), expected {world}")
     B, T, F, Lt = args.batch, 10, 1024, args.text_len
     batch = synth_batch(B, T, F, Lt, cfg.vocab_size, seed=1 + rank, device=dev)
     t_build = time.time() - t_build
@@ -352,11 +363,14 @@ def main():
                             "each sample's last token; NOT the headline: the reference computes those rows and the headline "
                             "counts them"}
         if world == 1 and full_cfg:
-            # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging), in the reference's order
-            # and with the opt-in one-step-delayed loss check
+            # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging) with NO opt-in set
+            # (`reference_order`: what the two-line swap of INTEGRATION.md gives -- the backward is enqueued before the host reads
+            # the loss, the non-finite check still precedes the update: loops.LossLog) and with the opt-ins
             n_l = max(4, min(args.steps, 8))
             extras["train_one_epoch"] = {"note": "frozenbilm_amd.main.train_one_epoch over synthetic batches that start on the "
-                                                 "host (CPU mask_tokens, H2D copies, loss logging): the loop, not the step body",
+                                                 "host (CPU mask_tokens, H2D copies, loss logging): the loop, not the step body; "
+                                                 "reference_order = the default loop, no opt-in (loss read after the backward "
+                                                 "is enqueued, before optimizer.step: same stop-before-update behaviour as main.py:73-84)",
                                          "reference_order": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False),
                                          "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True),
                                          "reference_order_graphed": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False,
@@ -364,9 +378,10 @@ def main():
                                          "delayed_loss_check_packed_rows": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l,
                                                                                               True, packed=True)}
 
-    cpu_baseline = None
+    cpu_baseline = cpu_baseline_cfg1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only=args.eval_forward)
+        cpu_baseline_cfg1 = measure_cpu_baseline_cfg1()
 
     if not args.no_extras and not args.eval_forward and world == 1 and full_cfg:
         # BASELINE configs[3] / configs[4] through the product's evaluate loops on the same model (last: the answer table is
@@ -402,10 +417,11 @@ def main():
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
             "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
             # data parallel: ranks RCCL's collectives ran over (0 = no reducer / not the nccl backend) and where in backward
-            # they are launched (parallel.GradReducer.overlap; FBL_DP_OVERLAP overrides the default for A/B runs)
+            # they are launched (parallel.GradReducer.overlap; --dp-overlap)
             "rccl_ranks": red.rccl_ranks if red is not None else 0, "dp_overlap": red.overlap if red is not None else None,
             "algorithmic_tflops_per_step": step_flops / 1e12,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "model_build_s": t_build, "box_calibration": box,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_cfg1": cpu_baseline_cfg1, "model_build_s": t_build,
+            "box_calibration": box,
         }
         out.update(extras)
         print(json.dumps(out))
@@ -813,6 +829,47 @@ def measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only):
             "sample": f"B={Bc} sequences (T=10, L={Lt}, S={T + Lt}) {'forward' if fwd_only else 'fwd+bwd'} through the fp32 CPU "
                       f"oracle, eval-mode math (no dropout): 1 warm-up pass ({warm:.1f} s) + {n_timed} timed "
                       f"({', '.join('%.1f' % x for x in times)} s), torch threads={int(phys)} (physical cores)"}
+
+
+def measure_cpu_baseline_cfg1():
+    """BASELINE configs[0] -- "BERT-base no-adapter, 4 synthetic videos (T=10x768 CLIP feats, L_text=64), MLM forward on CPU
+    reference path" -- timed on THIS box's host cores through the oracle restatement of model/bert.py:792-872 (oracle/bert_oracle.py,
+    pinned by golden G8 at these dimensions): SURVEY 8d inputs (B=4, video ~ N(0,1) [4,10,768], ids ~ U[1000,30522) [4,64], mask all
+    ones, seeded N(0,0.02) weights), forward only, 2 warm-up + 5 timed iterations, torch threads = physical cores."""
+    from oracle import bert_oracle as BO
+
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(phys))
+    try:
+        cfg = BO.BertOracleConfig()  # BertConfig() defaults: 12 layers, H=768, 12 heads, I=3072, vocab 30522; features_dim 768
+        P = BO.synth_params(cfg, seed=0, std=0.02)
+        g = torch.Generator().manual_seed(1)
+        Bc, T, Lt = 4, 10, 64
+        video = torch.randn(Bc, T, cfg.features_dim, generator=g)
+        ids = torch.randint(1000, cfg.vocab_size, (Bc, Lt), generator=g)
+        am, vm = torch.ones(Bc, Lt, dtype=torch.long), torch.ones(Bc, T, dtype=torch.long)
+        times = []
+        with torch.no_grad():
+            for i in range(7):
+                t = time.time()
+                out = BO.forward(cfg, P, ids, am, video, vm)
+                assert out["logits"].shape == (Bc, T + Lt, cfg.vocab_size)
+                if i >= 2:
+                    times.append(time.time() - t)
+        dt = sum(times) / len(times)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": Bc / dt, "unit": "samples/s", "cores": int(phys), "kind": "port", "loadavg": os.getloadavg()[0],
+            "logical_cpus": os.cpu_count(), "ms_per_forward": dt * 1e3,
+            "sample": f"BASELINE configs[0]: BERT-base (12L, H=768, vocab 30522) + linear_video, B={Bc}, T=10x768, L={Lt} (S={T + Lt}), MLM "
+                      f"forward through the fp32 CPU oracle (oracle/bert_oracle.py): 2 warm-up + {len(times)} timed iterations, torch "
+                      f"threads={int(phys)} (physical cores); survey container (8 vCPU): 27.8 samples/s"}
 
 
 if __name__ == "__main__":

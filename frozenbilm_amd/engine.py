@@ -12,7 +12,6 @@ on the fly, so the fp32 normalised tensor is never written to HBM, and ``t`` dou
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -88,6 +87,10 @@ class Engine:
                                "there is no CPU fallback")
         L.load()
         self.dev = dev
+        self.opts = dict(getattr(model, "engine_options", None) or {})
+        unknown = set(self.opts) - {"eager_logits", "side_stream", "pos_on_main", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group"}
+        if unknown:
+            raise ValueError(f"unknown engine_options: {sorted(unknown)}")
         self._build_flat()
         self._pack_frozen()
         self._relidx: Dict[int, torch.Tensor] = {}
@@ -111,19 +114,24 @@ class Engine:
         # concurrently with the big tiles; include/fbl.h): one per device, owned by the host side
         if L._AUX.get(dev.index if dev.index is not None else torch.cuda.current_device()) is None:
             L.set_aux_stream(torch.cuda.Stream(device=dev), dev)
-        # reference-faithful switch: fill the full [N, V] logits in every forward even when only the loss is consumed
-        self.eager_logits = os.environ.get("FBL_EAGER_LOGITS", "0") == "1"
+        # Engine options: `model.engine_options` (a dict read ONCE, when the engine is built; the product reads no environment
+        # variable).  Defaults are the shipped configuration; the other values exist for A/B measurements (tools/, tests):
+        #   eager_logits   fill the full [N, V] logits in every forward even when only the loss is consumed (reference-eager)
+        #   side_stream    False = single-stream execution;  pos_on_main: position-table gradient chain on the main stream
+        #   fold_dx        adapter dx folded into the dense dX GEMM;  dw_on_side: generic dW route on the side stream
+        #   fuse_tail      adapter up-projection + block dropout + residual as one epilogue (fbl_adapter_up_resid_fwd)
+        #   merge          dense layer + adapter down-projection as one GEMM;  dw_group: adapter gradient products per launch
+        o = self.opts
+        self.eager_logits = bool(o.get("eager_logits", False))
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
-        self.use_side_stream = os.environ.get("FBL_NO_SIDE_STREAM", "0") != "1"
-        self.pos_on_main = os.environ.get("FBL_POS_MAIN", "0") == "1"  # A/B switch: position-table gradient chain on the main stream (+2.5 ms)
-        self.fold_dx = os.environ.get("FBL_NO_FOLD_DX", "0") != "1"  # A/B switch: adapter dx folded into the dense dX GEMM
-        self.dw_on_side = os.environ.get("FBL_DW_SIDE", "0") == "1"  # A/B switch: generic dW route on the side stream
-        # adapter up-projection + block dropout + residual as ONE epilogue that writes the LayerNorm's pre-norm tensor
-        # (fbl_adapter_up_resid_fwd); FBL_NO_TAIL=1 = the separate up GEMM (fp32 y) + fbl_ln_fwd (A/B switch)
-        self.fuse_tail = os.environ.get("FBL_NO_TAIL", "0") != "1"
+        self.use_side_stream = bool(o.get("side_stream", True))
+        self.pos_on_main = bool(o.get("pos_on_main", False))
+        self.fold_dx = bool(o.get("fold_dx", True))
+        self.dw_on_side = bool(o.get("dw_on_side", False))
+        self.fuse_tail = bool(o.get("fuse_tail", True))
         L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
-        self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(os.environ.get("FBL_DW_GROUP", "16"))))  # adapter gradient products per launch (<= 16)
+        self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(o.get("dw_group", 16))))  # adapter gradient products per launch (<= 16)
 
     # ------------------------------------------------------------------ parameter plumbing
     def _build_flat(self):
@@ -139,7 +147,12 @@ class Engine:
             offs[n] = total
             total += _ru(named[n].numel(), 8)  # keep every view 32-byte aligned
         self.flat = torch.zeros(total, dtype=F32, device=self.dev)
-        self.flat_grad = torch.zeros(total, dtype=F32, device=self.dev)
+        # the gradient buffer is preceded by a few floats that travel with the first data-parallel bucket (the step's logged
+        # loss: parallel.GradReducer.stage_scalars); clip + Adam and p.grad only ever see `flat_grad`
+        from .parallel import SCALAR_SLOT
+
+        self.flat_grad_full = torch.zeros(SCALAR_SLOT + total, dtype=F32, device=self.dev)
+        self.flat_grad = self.flat_grad_full[SCALAR_SLOT:]
         self.flat_bf16 = torch.zeros(total, dtype=BF16, device=self.dev)
         self.offsets, self.order = offs, order
         self._adT_offs = {}
@@ -197,8 +210,8 @@ class Engine:
         # REVERSE layer order (index j = nL-1-layer) -- the order of the adapters in the flat trainable buffer.
         # (the merged GEMM needs the bottleneck unpadded, A % 64 == 0, and the segment boundary H on a wave's column
         # range, H % 64 == 0: include/fbl.h; otherwise neither the composed weights nor their per-step rebuild exist)
-        self.merge1 = bool(self.A1) and self.A1 % 64 == 0 and H % 64 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
-        self.merge2 = bool(self.A2) and self.A2 % 64 == 0 and H % 64 == 0 and os.environ.get("FBL_NO_MERGE", "0") != "1"
+        self.merge1 = bool(self.A1) and self.A1 % 64 == 0 and H % 64 == 0 and bool(self.opts.get("merge", True))
+        self.merge2 = bool(self.A2) and self.A2 % 64 == 0 and H % 64 == 0 and bool(self.opts.get("merge", True))
         self.WoT_rev = torch.empty(nL, H, H, dtype=BF16, device=dev)
         self.WdT_rev = torch.empty(nL, I, H, dtype=BF16, device=dev)
         if self.merge1:
@@ -995,7 +1008,7 @@ class Engine:
             run.dw_count += 1
             return dx
 
-        def dw_work(ws, cs_ws):  # generic route, launched right away: bottlenecks wider than 256 (or FBL_DW_SIDE=1)
+        def dw_work(ws, cs_ws):  # generic route, launched right away: bottlenecks wider than 256 (or engine_options dw_on_side)
             L.gemm_tn_acc(dyb, z, self.G[nm + ".up.weight"], ws, N=A, splitk=sk)      # dWu[H,A] += dy^T z
             L.gemm_tn_acc(dz, xin_b, self.G[nm + ".down.weight"], ws, M=A, splitk=sk)  # dWd[A,H] += dz^T x
             L.colsum(dz, self.G[nm + ".down.bias"], cs_ws, cols=A)

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, logged_step, tokenize, video_inputs
 from .util.misc import mask_tokens
 
 
@@ -34,12 +34,11 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
     if getattr(args, "packed_rows", False) and hasattr(model, "packed_rows"):
         model.packed_rows = True  # opt-in: ragged batches without the padding rows behind each sample's last token
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
-    log = LossLog(run, "mlm_loss", delayed=getattr(args, "delayed_loss_check", False))
+    log = LossLog(run, "mlm_loss", delayed=getattr(args, "delayed_loss_check", False), reducer=getattr(model, "_reducer", None))
     for i_batch, batch_dict in run:
         feed = _prepare(batch_dict, tokenizer, device, args, step_seed=run.global_step(i_batch) + 1)
         loss = model(**feed)["loss"]
-        log(loss)  # (main.py:70-78; one step late with args.delayed_loss_check)
-        optimizer_step(loss, optimizer, model, max_norm)
+        logged_step(log, loss, optimizer, model, max_norm)  # main.py:70-86 (see loops.LossLog for the order of the loss read)
         run.schedule(optimizer, i_batch)
     return run.finish()
 
@@ -50,7 +49,7 @@ def evaluate(model, tokenizer, data_loader, device, args):
     if getattr(args, "packed_rows", False) and hasattr(model, "packed_rows"):
         model.packed_rows = True
     run = EpochRunner(data_loader, args, "Val:")
-    log = LossLog(run, "mlm_loss", stop_on_nonfinite=False, delayed=getattr(args, "delayed_loss_check", False))
+    log = LossLog(run, "mlm_loss", stop_on_nonfinite=False, delayed=True)  # (nothing to protect: read one batch late)
     with frozen_weights(model):
         for _, batch_dict in run:
             log(model(**_prepare(batch_dict, tokenizer, device, args))["loss"])

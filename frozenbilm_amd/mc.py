@@ -11,7 +11,7 @@ from functools import reduce
 import torch
 import torch.nn.functional as F
 
-from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, logged_step, tokenize, video_inputs
 from .util import dist
 from .videoqa import answer_logits
 
@@ -64,12 +64,11 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, arg
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
     # several forwards feed one step: under data parallelism the gradient exchange waits for the last backward pass
     reducer = getattr(model.engine(), "reducer", None) if hasattr(model, "engine") else None
-    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False))
+    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False), reducer=getattr(model, "_reducer", None))
     for i_batch, batch_dict in run:
         scores = candidate_scores(model, tokenizer, batch_dict, device, args)
         loss = mc_loss(scores, batch_dict["answer_id"].to(device), data_loader.dataset.mc)
-        log(loss)
-        optimizer_step(loss, optimizer, model, max_norm, reducer=reducer)
+        logged_step(log, loss, optimizer, model, max_norm, reducer=reducer)
         run.schedule(optimizer, i_batch)
         run.log(lr=optimizer.param_groups[0]["lr"])
     return run.finish()

@@ -223,6 +223,7 @@ class DebertaV2ForMaskedLM(nn.Module):
         emb = self._module("deberta.embeddings")
         emb.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
         self._engine = None
+        self.engine_options = {}  # read once when the engine is built (engine.Engine.__init__ lists the keys; defaults = shipped)
         self.inference_graphs = False  # opt-in: replay the `logit_rows` inference forward as one hipGraph (_graph_forward)
         self.training_graphs = False  # opt-in: the MLM training step as two replayed hipGraphs (train_graph.py)
         # opt-in: ragged batches run without the padding rows behind each sample's last used position (engine.Packing) whenever

@@ -34,6 +34,7 @@ from .engine import Run
 F32 = torch.float32
 ROW_BUCKET = 256  # capacity granularity of the labelled-row list
 MAX_GRAPHS = 4    # captured (batch shape, row capacity) configurations kept per model (each owns one step's activations)
+MAX_CAPTURES = 12  # captures per model before the feature switches itself off with a warning (a shape-static loop needs 1-3)
 
 
 class _Replay(torch.autograd.Function):
@@ -123,11 +124,10 @@ class GraphedStep:
     def run_backward(self, gloss):
         eng = self.eng
         self.gloss.copy_(gloss.detach().to(F32).reshape(()))
-        first, last = eng.named[eng.order[0]], eng.named[eng.order[-1]]
-        if not (first.grad is not None and last.grad is not None and first.grad.data_ptr() == eng.G[eng.order[0]].data_ptr()
-                and last.grad.data_ptr() == eng.G[eng.order[-1]].data_ptr()):
-            eng.attach_grads()  # (300 parameters: skipped while p.grad still are the views of the flat buffer -- zero_grad
-            #                      (set_to_none=True) or a foreign .grad on either end brings the full pass back)
+        named, G = eng.named, eng.G
+        if not all(named[n].grad is not None and named[n].grad.data_ptr() == G[n].data_ptr() for n in eng.order):
+            eng.attach_grads()  # (skipped while every p.grad still is its view of the flat buffer -- zero_grad(set_to_none=True)
+            #                      or a foreign / dropped .grad on ANY parameter brings the full pass back; ~300 pointer compares)
         self.g_bwd.replay()
         self.pending_backward = False
         if eng.reducer is not None:
@@ -140,6 +140,11 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
     cannot be served from a graph (the caller takes the eager path)."""
     if labels is None or input_ids is None or not torch.is_grad_enabled():
         return None
+    # Data parallel: a rank served by a graph exchanges ONE [0, n) collective after the replay (run_backward); a rank that
+    # falls back to the eager step (no labelled row in its shard, a failed capture) must issue the same pattern, or the ranks'
+    # collectives no longer match in count and size.  While training_graphs is on the reducer therefore runs in "after" mode.
+    if eng.reducer is not None and eng.reducer.overlap != "after":
+        eng.reducer.overlap = "after"
     dev = eng.dev
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
@@ -174,9 +179,24 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
             del cache[k]
         while len(cache) >= MAX_GRAPHS:
             del cache[next(iter(cache))]
+        # a loop whose batch shapes keep changing (text padded to the longest sample, label counts crossing a row bucket) would
+        # capture -- one eager warm-up step plus two captures, ~10 GB of pooled activations each -- and evict continuously
+        n_cap = model.__dict__.get("_train_graph_captures", 0) + 1
+        model.__dict__["_train_graph_captures"] = n_cap
+        if n_cap > MAX_CAPTURES:
+            import warnings
+
+            warnings.warn(f"model.training_graphs: {n_cap} distinct (batch shape, label capacity) configurations seen -- the loop "
+                          "is not shape-static (pad the text to a fixed length / bucket it); staying on the eager path")
+            model.training_graphs = False
+            cache.clear()
+            return None
         # one eager step of this shape first: lazy initialisations (kernel attributes, workspaces, allocator warm-up) happen
-        # outside the capture.  It leaves no trace: the caller's accumulated gradients and the mask-stream position are restored.
+        # outside the capture.  It leaves no trace: the caller's accumulated gradients, the STATE of every p.grad (None stays
+        # None: the next attach_grads then zero-fills as it would have; a view of the flat buffer gets its old contents back)
+        # and the mask-stream position are restored.
         saved = eng.flat_grad.clone()
+        grads_before = [eng.named[n].grad for n in eng.order]
         red, eng.reducer = eng.reducer, None  # (no collectives: ranks may capture at different steps -- their row capacities differ)
         try:
             res = eng.run(feed["input_ids"], feed["attention_mask"], feed.get("video"), feed.get("video_mask"), feed["labels"],
@@ -185,7 +205,9 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
         finally:
             eng.reducer = red
         eng.flat_grad.copy_(saved)
-        del res, saved
+        for n, g in zip(eng.order, grads_before):
+            eng.named[n].grad = g
+        del res, saved, grads_before
         torch.cuda.synchronize(dev)
         model.step_seed = seed0
         step = GraphedStep(model, eng, feed, r_cap)

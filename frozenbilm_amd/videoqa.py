@@ -11,7 +11,7 @@ from functools import reduce
 import torch
 import torch.nn.functional as F
 
-from .loops import EpochRunner, LossLog, frozen_weights, optimizer_step, tokenize, video_inputs
+from .loops import EpochRunner, LossLog, frozen_weights, logged_step, tokenize, video_inputs
 from .util import dist
 
 
@@ -69,7 +69,7 @@ def topk_agreement(logits, answer_id, dataset_name, thresholds):
 def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dataset_name, args, max_norm: float = 0):
     model.train()
     run = EpochRunner(data_loader, args, "Epoch: [{}]".format(epoch), epoch)
-    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False))
+    log = LossLog(run, "cls_loss", delayed=getattr(args, "delayed_loss_check", False), reducer=getattr(model, "_reducer", None))
     for i_batch, batch_dict in run:
         video, video_mask = video_inputs(batch_dict, device)
         encoded = tokenize(tokenizer, batch_dict["text"], args)
@@ -77,8 +77,7 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, dat
                        attention_mask=encoded["attention_mask"].to(device))
         logits = mask_row_logits(output["logits"], encoded["input_ids"], tokenizer, args)
         loss = vqa_loss(logits, batch_dict["answer_id"].to(device), dataset_name)
-        log(loss)
-        optimizer_step(loss, optimizer, model, max_norm)
+        logged_step(log, loss, optimizer, model, max_norm)
         run.schedule(optimizer, i_batch)
         run.log(lr=optimizer.param_groups[0]["lr"])
     return run.finish()

@@ -23,8 +23,6 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     config = sys.argv[3] if len(sys.argv) > 3 else "tiny"
     xl = config == "xl4"
-    if xl:
-        os.environ["FBL_DW_GROUP"] = "4"  # read at engine construction: 4 adapters per gradient launch
     multi = torch.cuda.device_count() >= world
     dev = torch.device("cuda", rank if multi else 0)
     torch.cuda.set_device(dev)
@@ -40,7 +38,8 @@ def main():
         cfg.num_hidden_layers, cfg.vocab_size = 4, 4096
     else:
         cfg = _tiny_cfg()
-    m = build(cfg, O.synth_params(cfg, seed=41, std=0.02 if xl else 0.05, ln_jitter=0.1))  # eval mode: dropout off, gradients on
+    # eval mode: dropout off, gradients on; xl4: 4 adapters per gradient launch (read when the engine is built)
+    m = build(cfg, O.synth_params(cfg, seed=41, std=0.02 if xl else 0.05, ln_jitter=0.1), engine_options={"dw_group": 4} if xl else None)
     m.to(dev)
     if config == "tiny+packed":  # model.packed_rows: every rank packs its own ragged shard (different row counts per rank)
         m.packed_rows = True
@@ -58,6 +57,30 @@ def main():
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
     n_coll = len(red.last_launched)
+    # a third step with the loops' loss bookkeeping: the logged loss rides in front of the first gradient bucket (no collective
+    # of its own), and the host reads the rank-averaged value between backward and the update (loops.LossLog.begin / check)
+    from frozenbilm_amd.loops import LossLog
+
+    class _Meter:
+        loss_log = None
+        vals = None
+
+        def log(self, **kw):
+            self.vals = kw
+
+    meter = _Meter()
+    log = LossLog(meter, "mlm_loss", reducer=red)
+    m.zero_grad(set_to_none=False)
+    out = m(**mine)
+    c0 = red.n_collectives
+    log.begin(out.loss)
+    out.loss.backward()
+    log.check()
+    extra = red.n_collectives - c0 - len(red.last_launched)
+    mean_loss = torch.tensor([out.loss.item()], device=dev)
+    dist.all_reduce(mean_loss)
+    loss_rides = (meter.vals is not None and abs(meter.vals["loss"] - mean_loss.item() / world) < 1e-6
+                  and abs(meter.vals["mlm_loss"] - meter.vals["loss"]) < 1e-12)
     spans = sorted(red.last_launched)
     covers = spans[0][0] == 0 and spans[-1][1] == red.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     print(f"[dp_worker] rank {rank}/{world}: backend {dist.get_backend()}, RCCL saw {red.rccl_ranks} ranks, overlap "
@@ -72,7 +95,8 @@ def main():
     if rank == 0:
         torch.save({"grads": grads, "losses": losses, "backend": dist.get_backend(), "collectives": n_coll,
                     "rccl_ranks": red.rccl_ranks, "overlap": red.overlap, "covers": covers, "launch_order": list(red.last_launched),
-                    "ranks_agree": bool(ok.item() == 1.0), "world": world}, sys.argv[1])
+                    "ranks_agree": bool(ok.item() == 1.0), "world": world, "loss_rides": bool(loss_rides),
+                    "extra_collectives_for_the_loss": int(extra)}, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()
 

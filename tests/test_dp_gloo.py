@@ -70,6 +70,35 @@ def _worker(rank, world, port, q):
                 red.finish()
                 ok &= torch.equal(flat, mine) and not red.pending
         ok &= torch.allclose(flat, expect, atol=1e-6) and red.last_launched == [(0, n)]
+        # the step's logged loss rides in front of the first bucket (util/dist.py:89-113 is a collective of its own
+        # in the reference): same number of collectives as without it, averaged value on every rank, gradients unchanged
+        from frozenbilm_amd.parallel import SCALAR_SLOT
+
+        full = torch.zeros(SCALAR_SLOT + n)
+        fl = full[SCALAR_SLOT:]
+        for mode in ("backward", "attention_windows", "after"):
+            fl.copy_(mine)
+            rs = GradReducer(fl, ends, min_bucket_elems=64, overlap=mode, flat_full=full)
+            plain = GradReducer(mine.clone(), ends, min_bucket_elems=64, overlap=mode)
+            for r_ in (rs, plain):
+                if r_ is rs:
+                    r_.stage_scalars(torch.tensor([3.0 + rank]))
+                    ok &= r_.take_scalars() is None  # nothing exchanged yet
+                for i_, key in enumerate(("head", "layer2", "layer1", "conv", "layer0", "relln", "emb")):
+                    r_.ready(key)
+                    if i_ == 1:
+                        r_.window()
+                r_.finish()
+            ok &= rs.n_collectives == plain.n_collectives == len(rs.last_launched)  # the loss added none
+            got = rs.take_scalars()
+            ok &= got is not None and abs(got[0] - 3.5) < 1e-6 and rs.take_scalars() is None
+            ok &= torch.allclose(fl, expect, atol=1e-6)
+            # a second step without a staged loss: plain exchange, the slot is left alone
+            fl.copy_(mine)
+            for key in ("head", "layer2", "layer1", "conv", "layer0", "relln", "emb"):
+                rs.ready(key)
+            rs.finish()
+            ok &= torch.allclose(fl, expect, atol=1e-6) and rs.take_scalars() is None
         # DP equivalence: all-reduced per-rank gradients == single-process gradients of the mean of the
         # per-rank mean losses, on the oracle model with the flat layout / bucket order of the engine
         from oracle import deberta_oracle as O

@@ -18,7 +18,7 @@ from tests.gpu_refs import stats  # noqa: E402
 DEV = "cuda"
 
 
-def build(cfg: O.OracleConfig, P, train=False):
+def build(cfg: O.OracleConfig, P, train=False, engine_options=None):
     from frozenbilm_amd.model.config import DebertaV2Config
     from frozenbilm_amd.model.deberta import DebertaV2ForMaskedLM
 
@@ -31,6 +31,8 @@ def build(cfg: O.OracleConfig, P, train=False):
     missing, unexpected = m.load_state_dict(P, strict=False)
     assert not unexpected, unexpected
     assert all("position_ids" in k for k in missing), missing
+    if engine_options:
+        m.engine_options = dict(engine_options)
     m.to(DEV)
     m.train(train)
     return m
@@ -827,8 +829,8 @@ def _run_two_ranks(tmp_path, overlap, config):
     return torch.load(out_file)
 
 
-def _single_process_reference(cfg, P, L):
-    m = build(cfg, P)
+def _single_process_reference(cfg, P, L, engine_options=None):
+    m = build(cfg, P, engine_options=engine_options)
     batch = synth_batch(cfg, B=4, L=L, seed=9)
     m.zero_grad(set_to_none=False)
     losses = []
@@ -849,6 +851,8 @@ def test_two_rank_data_parallel_equivalence_on_the_hip_engine(tmp_path, overlap)
     the attention-backward windows, or once after backward."""
     got = _run_two_ranks(tmp_path, overlap, "tiny")
     assert got["ranks_agree"] and got["world"] == 2 and got["covers"] and got["overlap"] == overlap
+    # the logged loss of a loop step travels with the first bucket: rank-averaged on the host, no collective of its own
+    assert got["loss_rides"] and got["extra_collectives_for_the_loss"] == 0, got
     # ("attention_windows" at the tiny size: its six adapters never fill a gradient group, every stage becomes final after
     #  the last window -- one collective; the xlarge-dimension test below sees windows that carry buckets)
     want_n = {"backward": lambda n: n >= 3, "after": lambda n: n == 1, "attention_windows": lambda n: n >= 1}[overlap]
@@ -888,12 +892,7 @@ def test_two_rank_data_parallel_at_xlarge_dimensions(tmp_path):
     print(f"backend {got['backend']} (RCCL ranks: {got['rccl_ranks']}), launch order {order}")
     cfg = O.OracleConfig()
     cfg.num_hidden_layers, cfg.vocab_size = 4, 4096
-    import os
-    os.environ["FBL_DW_GROUP"] = "4"
-    try:
-        want, _ = _single_process_reference(cfg, O.synth_params(cfg, seed=41, std=0.02, ln_jitter=0.1), 96)
-    finally:
-        del os.environ["FBL_DW_GROUP"]
+    want, _ = _single_process_reference(cfg, O.synth_params(cfg, seed=41, std=0.02, ln_jitter=0.1), 96, engine_options={"dw_group": 4})
     worst = max(_rel_fro(got["grads"][n], want[n]) for n in want)
     print(f"worst relative difference reduced-vs-single-process at xlarge dims: {worst:.2e}")
     assert worst < 1e-5, worst
@@ -962,17 +961,22 @@ def test_delayed_loss_check_gives_the_same_epoch_statistics():
     assert torch.equal(finals[0], finals[1])
 
 
-def test_graphed_training_step_equals_the_eager_step():
+@pytest.mark.parametrize("set_to_none", [False, True])
+def test_graphed_training_step_equals_the_eager_step(set_to_none):
     """model.training_graphs: forward and backward of the MLM step replayed as two hipGraphs (train_graph.py).  Same kernels,
     same inputs, same seeds (per-site constants + the device word rewritten before every replay): three optimizer steps on
     three different batches leave exactly the parameters the eager loop leaves; dropout is live and differs between steps;
     `.logits` of a graphed step are filled on access; a second forward before backward is refused; an eval forward and a
-    shape change in between do not disturb the captured graphs."""
+    shape change in between do not disturb the captured graphs.  set_to_none=True: the standard `opt.zero_grad()` idiom before
+    the forward -- every p.grad is None when a new shape is captured, and the eager warm-up step in front of the capture must
+    leave them None (it used to leave views of stale gradients behind, which the first replay accumulated onto)."""
     from frozenbilm_amd.optim import FusedAdam
 
     cfg = _tiny_cfg()
     P = O.synth_params(cfg, seed=47, std=0.05, ln_jitter=0.1)
-    batches = [to_dev(synth_batch(cfg, B=4, L=40, seed=60 + i)) for i in range(3)]
+    # (the third batch has another shape: its capture -- and the eager warm-up step in front of it -- happens while the flat
+    #  gradient buffer still holds the gradients of step 2)
+    batches = [to_dev(synth_batch(cfg, B=4, L=40 if i < 2 else 56, seed=60 + i)) for i in range(3)]
     other = to_dev(synth_batch(cfg, B=2, L=24, seed=70))
     results = []
     for graphs in (False, True):
@@ -982,7 +986,11 @@ def test_graphed_training_step_equals_the_eager_step():
         opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.95))
         losses = []
         for i, b in enumerate(batches):
-            opt.zero_grad(set_to_none=False)
+            if set_to_none:
+                for p_ in m.parameters():
+                    p_.grad = None
+            else:
+                opt.zero_grad(set_to_none=False)
             out = m(**b)
             if graphs and i == 1:
                 with pytest.raises(RuntimeError):
@@ -999,7 +1007,7 @@ def test_graphed_training_step_equals_the_eager_step():
                 m.train()
         results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, m.step_seed))
         if graphs:
-            assert len(m.__dict__.get("_train_graphs", {})) == 1
+            assert len(m.__dict__.get("_train_graphs", {})) == 2
     (l0, p0, s0), (l1, p1, s1) = results
     assert s0 == s1 == 3
     assert all(abs(a - b) < 1e-6 for a, b in zip(l0, l1)), (l0, l1)
