@@ -17,6 +17,19 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 POISON_GT = False
+_RANGE = {}
+
+
+def _relidx_range(S, cfg):
+    """(first, count) of the position-table rows the relative-index map of a length-S sequence can touch (host integers,
+    computed once per sequence length)"""
+    key = (S, cfg.position_buckets, cfg.max_rel, cfg.att_span)
+    if key not in _RANGE:
+        from .model.relpos import rel_index_vector
+
+        rv = rel_index_vector(S, cfg.position_buckets, cfg.max_rel, cfg.att_span)
+        _RANGE[key] = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1)
+    return _RANGE[key]
 
 
 def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
@@ -46,11 +59,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
-    from .model.relpos import rel_index_vector
-    rv = rel_index_vector(S, eng.cfg.position_buckets, eng.cfg.max_rel, eng.cfg.att_span) if hasattr(eng, "cfg") else None
-    rmin, rcnt = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1) if rv is not None else (0, span2)
+    rmin, rcnt = _relidx_range(S, eng.cfg)
     # |i-j| < lin: identity buckets, relidx injective (model/deberta.py:578-589: mid = bucket_size // 2)
-    lin = 0 if rv is None else (eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30)
+    lin = eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30
     lin_a = min(lin, span2 // 2) if eng.cfg.position_buckets > 0 else 0  # affine addressing of kernel A: identity buckets only
     L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
                          B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)

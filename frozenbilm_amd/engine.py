@@ -971,7 +971,7 @@ class Engine:
             dt_full[N:].zero_()
         dyb = dy_out if dy_out is not None else (torch.empty(N, H, dtype=BF16, device=self.dev) if want_dy_bf16 else None)
         L.ln_bwd(dout, norm.t, norm.stats, norm.gamma, rowmask=norm.rowmask, p_drop=p_drop, seed=seed, out_dt=dt,
-                 out_dy_bf16=dyb, dgamma=self.G[name + ".weight"], dbeta=self.G[name + ".bias"], dysum=dysum,
+                 out_dy_bf16=dyb, dgamma=self.G.get(name + ".weight"), dbeta=self.G.get(name + ".bias"), dysum=dysum,
                  ws=self._ln_ws)
         if tail:
             return dt, dyb, dt_full
@@ -1063,8 +1063,8 @@ class Engine:
             run.dw_ready_keys[:] = still
 
     def _layer_bwd(self, run, sv: "LayerSave", dout: torch.Tensor):
-        """Backward of one layer execution.  dout: fp32 grad of its output.  Returns (dq_in, dkv_in) fp32 -- equal
-        streams are returned summed as (dx, None) for ordinary encoder layers."""
+        """Backward of one layer execution.  dout: fp32 grad of its output.  Returns (dx, None) for ordinary encoder layers (one
+        input stream) and (dq_in fp32, [dK | dV] bf16 operand of the key/value-stream gradient) for the decoder form."""
         li = sv.li
         W, ad = self.Lw[li], self.ad[li]
         H, I, dev = self.H, self.I, self.dev
@@ -1109,16 +1109,20 @@ class Engine:
             dx = torch.empty(N, H, dtype=F32, device=dev)
             L.gemm(dqkv, W["WqkvT"], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dx)
             return dx, None
+        # Enhanced mask decoder (model/deberta.py:1382-1412): the query stream and the key/value stream differ.  Returns the
+        # gradient of the query stream and, in place of the key/value-stream gradient, the bf16 [dK | dV] operand it is the
+        # product of -- the caller chains both passes' products into ONE accumulator through the GEMM epilogues
+        # (dx = dq_first + dkv_second + dkv_first: no stand-alone additions of [N, H] fp32 tensors).
         dq = torch.empty(N, H, dtype=F32, device=dev)
         L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dq)
-        dkv = torch.empty(N, H, dtype=F32, device=dev)
-        L.gemm(dqkv[:, H:], W["WqkvT"][:, H:], out_f32=dkv)
-        return dq, dkv
+        return dq, dqkv[:, H:]
 
     def _pos_grad_async(self, run, sv, pst, W):
         from .attn_bwd import pos_table_grads
 
         H = self.H
+        if "deberta.encoder.LayerNorm.weight" not in self.G:  # ft_ln=False: nothing trainable sits behind the position tables
+            return
 
         def work(ws):
             dpos = pos_table_grads(self, pst, ws)
@@ -1244,12 +1248,20 @@ class Engine:
         run.dR = torch.zeros(self.span2, H, dtype=F32, device=dev)
         # ---- EMD: two executions of the last layer, newest first
         layers = run.layers
-        d_kv_last = None
+        dkv_ops = []
         for _ in range(2):
             sv = layers.pop()
-            dq, dkv = self._layer_bwd(run, sv, dq)
-            d_kv_last = dkv if d_kv_last is None else d_kv_last.add_(dkv)
-        dx = dq.add_(d_kv_last)  # q0 = pos_emb + hs[-2]: the query-stream grad flows into hs[-2] too
+            dq, dkv_op = self._layer_bwd(run, sv, dq)
+            dkv_ops.append(dkv_op)
+        # q0 = pos_emb + hs[-2]: the query-stream gradient flows into hs[-2] too, next to both passes' key/value-stream
+        # gradients [dK | dV] . [Wk ; Wv] -- accumulated by the epilogues of those two GEMMs
+        WkvT = self.Lw[self.nL - 1]["WqkvT"][:, H:]
+        dx = dq
+        for op in dkv_ops:
+            acc = torch.empty(N, H, dtype=F32, device=dev)
+            L.gemm(op, WkvT, aux=dx, aux_kind=L.AUX_ADD_F32, out_f32=acc)
+            dx = acc
+        del dkv_ops
         stage_done(f"layer{self.nL - 1}")
         # ---- encoder layers nL-2 .. 0
         while layers:
@@ -1274,8 +1286,9 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self.side)  # all adapter dW/db are in the flat grad buffer
         # ---- relative-position LayerNorm (receives grads from every layer execution)
         rn = run.rel_norm
-        L.ln_bwd(run.dR, rn.t, rn.stats, rn.gamma, dgamma=self.G["deberta.encoder.LayerNorm.weight"],
-                 dbeta=self.G["deberta.encoder.LayerNorm.bias"], ws=self._ln_ws)
+        if "deberta.encoder.LayerNorm.weight" in self.G:
+            L.ln_bwd(run.dR, rn.t, rn.stats, rn.gamma, dgamma=self.G.get("deberta.encoder.LayerNorm.weight"),
+                     dbeta=self.G.get("deberta.encoder.LayerNorm.bias"), ws=self._ln_ws)
         if red:
             red.ready("relln")
         # ---- embeddings: dropout -> *mask -> LN ; linear_video
@@ -1284,7 +1297,7 @@ class Engine:
         en = run.emb_norm
         dt0 = torch.empty(N, H, dtype=F32, device=dev)
         L.ln_bwd(dx, en.t, en.stats, en.gamma, rowmask=en.rowmask, out_dt=dt0,
-                 dgamma=self.G["deberta.embeddings.LayerNorm.weight"], dbeta=self.G["deberta.embeddings.LayerNorm.bias"],
+                 dgamma=self.G.get("deberta.embeddings.LayerNorm.weight"), dbeta=self.G.get("deberta.embeddings.LayerNorm.bias"),
                  ws=self._ln_ws)
         if T:
             if pk is None:
@@ -1310,8 +1323,8 @@ class Engine:
         cn = run.conv_norm
         dt = torch.empty(N, H, dtype=F32, device=dev)
         L.ln_bwd(dout, cn.t, cn.stats, cn.gamma, rowmask=cn.rowmask, out_dt=dt,
-                 dgamma=self.G["deberta.encoder.conv.LayerNorm.weight"],
-                 dbeta=self.G["deberta.encoder.conv.LayerNorm.bias"], ws=self._ln_ws)
+                 dgamma=self.G.get("deberta.encoder.conv.LayerNorm.weight"),
+                 dbeta=self.G.get("deberta.encoder.conv.LayerNorm.bias"), ws=self._ln_ws)
         dc = torch.empty(N, H, dtype=BF16, device=dev)
         L.dropout_gelu_bwd(dt, run.conv_c, run.p_hid, run.seed_conv, out_bf16=dc)
         dcol = torch.empty(N, 3 * H, dtype=F32, device=dev)

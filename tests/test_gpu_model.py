@@ -18,7 +18,7 @@ from tests.gpu_refs import stats  # noqa: E402
 DEV = "cuda"
 
 
-def build(cfg: O.OracleConfig, P, train=False, engine_options=None):
+def build(cfg: O.OracleConfig, P, train=False, engine_options=None, ft_ln=True):
     from frozenbilm_amd.model.config import DebertaV2Config
     from frozenbilm_amd.model.deberta import DebertaV2ForMaskedLM
 
@@ -27,7 +27,7 @@ def build(cfg: O.OracleConfig, P, train=False, engine_options=None):
                         max_position_embeddings=cfg.max_position_embeddings, position_buckets=cfg.position_buckets,
                         layer_norm_eps=cfg.layer_norm_eps, conv_kernel_size=cfg.conv_kernel_size)
     m = DebertaV2ForMaskedLM(c, max_feats=cfg.max_feats, features_dim=cfg.features_dim, ds_factor_attn=cfg.ds_factor_attn,
-                             ds_factor_ff=cfg.ds_factor_ff, n_ans=cfg.n_ans)
+                             ds_factor_ff=cfg.ds_factor_ff, n_ans=cfg.n_ans, ft_ln=ft_ln)
     missing, unexpected = m.load_state_dict(P, strict=False)
     assert not unexpected, unexpected
     assert all("position_ids" in k for k in missing), missing
@@ -545,6 +545,55 @@ def test_train_mode_parity_with_replayed_dropout_masks(cfg, B, Lt):
     assert results[False][0] == results[True][0]
     for n in results[False][2]:
         assert torch.equal(results[False][2][n], results[True][2][n]), n
+
+
+@pytest.mark.parametrize("ds_attn,ds_ff,ft_ln", [(0, 0, True), (8, 8, False), (0, 8, True), (8, 0, False)],
+                         ids=["no-adapters", "ft_ln-off", "ffn-adapter-only", "attn-adapter-only+ft_ln-off"])
+def test_freeze_policy_flag_variants_vs_oracle(ds_attn, ds_ff, ft_ln):
+    """The constructor flags of the reference's ablations on the GPU: `ds_factor_attn / ds_factor_ff = 0` (no adapter at that
+    site, model/deberta.py:252,326) and `ft_ln=False` (LayerNorms frozen, :1152-1158; args.py:333-337).  Trainable set = the
+    reference's substring rule; logits / loss / every trainable gradient against the oracle (bf16-operand mode, the GPU's ReLU
+    gates), frozen parameters receive no gradient, train mode included (dropout masks replayed)."""
+    from tests.dropout_replay import ReplayedMasks
+
+    cfg = _tiny_cfg(ds_factor_attn=ds_attn, ds_factor_ff=ds_ff)
+    P = O.synth_params(cfg, seed=61, std=0.05, ln_jitter=0.1)
+    B, Lt = 4, 50
+    batch = synth_batch(cfg, B=B, L=Lt, seed=13)
+    for train in (False, True):
+        torch.manual_seed(99)
+        m = build(cfg, P, train=train, ft_ln=ft_ln)
+        want_train = sorted(k for k in P if O.is_trainable(k, ft_ln=ft_ln))
+        assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == want_train
+        assert want_train, "nothing trainable"
+        out = m(**to_dev(batch))
+        run = out.__dict__["_run"]
+        gates = _gates_of(run, cfg)
+        masks = None
+        if train:
+            c = m.config
+            masks = ReplayedMasks(run, cfg, cfg.num_attention_heads, c.hidden_dropout_prob, c.attention_probs_dropout_prob,
+                                  m.adapter_dropout)
+        out.loss.backward()
+        for k, v in P.items():
+            v.requires_grad_(O.is_trainable(k, ft_ln=ft_ln))
+            v.grad = None
+        import contextlib
+
+        with O.bf16_operands(), O.adapter_gates([g_.view(B, -1, g_.shape[-1]) for g_ in gates]), \
+                (O.dropout_masks(masks) if train else contextlib.nullcontext()):
+            ref = O.forward(P, cfg, **batch)
+            ref["loss"].backward()
+        if train:
+            assert masks.exhausted(), masks.asked
+        assert abs(out.loss.item() - ref["loss"].item()) < 2e-2
+        assert (out.logits.float().cpu() - ref["logits"]).abs().max().item() < 5e-2
+        worst = sorted(((round(_rel_fro(p.grad.float().cpu(), P[n].grad), 4), n) for n, p in m.named_parameters() if p.requires_grad),
+                       reverse=True)
+        print(f"flags ds_attn={ds_attn} ds_ff={ds_ff} ft_ln={ft_ln} train={train}: worst grads {worst[:3]}")
+        assert worst[0][0] < 2e-2, worst[:6]
+        assert all(p.grad is None for n, p in m.named_parameters() if not p.requires_grad)
+        del m, out, run
 
 
 @pytest.mark.slow
