@@ -70,15 +70,25 @@ __device__ __forceinline__ void gelu_and_grad(float x, float* y, float* dy) {
 }
 
 // Counter-based dropout RNG: keep decision is a pure function of (seed, element index), so backward
-// regenerates the mask instead of storing it.  Two rounds of a 64->32 bit multiply-xorshift mixer.
+// regenerates the mask instead of storing it.  32-bit arithmetic only: integer multiplies are quarter rate on CDNA and a
+// 64 x 64 -> 64 bit product is four of them -- the first version of this mixer (three 64-bit multiplies, ~230 issue cycles per
+// element and wave) was half of the run time of the HBM-bound row kernels that regenerate a mask per element (LayerNorm
+// backward, adapter tail).  Now: index * odd constant, seed folded in by XOR (non-linear against the multiplies around it: two
+// sites / steps do not see shifted copies of one sequence), then the two multiply-xorshift rounds of the "lowbias32"
+// finaliser with the seed's upper word entering between them.  3 multiplies, ~85 issue cycles.  Restated on the host by
+// tests/dropout_replay.py (train-mode parity against the oracle with replayed masks).
 __device__ __forceinline__ uint32_t fbl_hash(uint64_t seed, uint64_t idx) {
-  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)x;
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u;
+  h ^= (uint32_t)seed;
+  h ^= (hi << 13) | (hi >> 19);
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h ^= (uint32_t)(seed >> 32);
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
 }
 // returns the multiplicative factor: 0 (dropped) or 1/(1-p) (kept); p == 0 -> 1
 __device__ __forceinline__ float fbl_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {

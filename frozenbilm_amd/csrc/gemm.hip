@@ -483,10 +483,6 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     g.drop_inv_keep = 1.f / (1.f - p_drop);
   }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
-  // tall-and-narrow problems (the adapter backward's dz = (dy . Wu) (*) gate): narrow operand resident in LDS, gemm_narrow.hip
-  static const int narrow_on = FBL_ENV_INT("FBL_GEMM_NARROW", 1);
-  if (narrow_on && batch == 1 && !accumulate && !tail && bias == nullptr && gemm_narrow_eligible(g, act, aux_kind))
-    return launch_gemm_narrow(g, aux_kind, device_cu_count(), (hipStream_t)stream);
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = FBL_ENV_INT("FBL_GEMM_SMALL", 0);
   const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0 || tail) && (seg_n <= 0 || (seg_n & 255) == 0) &&

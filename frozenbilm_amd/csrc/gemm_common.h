@@ -447,10 +447,5 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
 int launch_gemm8(const GemmArgs& g, int act, int aux_kind, int rows, dim3 grid, hipStream_t stream);  // rows: 256 / 224 / 128
 bool gemm8_eligible(const GemmArgs& g);
 
-// Tall-and-narrow problems (N <= 192, K <= 1536: the adapter backward's dz GEMM) with the narrow operand resident in LDS
-// (gemm_narrow.hip).
-bool gemm_narrow_eligible(const GemmArgs& g, int act, int aux_kind);
-int launch_gemm_narrow(const GemmArgs& g, int aux_kind, int n_cu, hipStream_t stream);
-
 
 }  // namespace fblgemm

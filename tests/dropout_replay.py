@@ -1,7 +1,7 @@
 """Rebuild, on the host, the dropout masks a HIP training forward drew (test infrastructure only).
 
 The HIP path never stores a dropout mask: every seeded kernel derives its keep decisions from a counter-based hash of
-(seed, element index) and the backward regenerates them (frozenbilm_amd/csrc/fbl_common.h:74-103, attn_common.h "attention-
+(seed, element index) and the backward regenerates them (frozenbilm_amd/csrc/fbl_common.h fbl_hash / fbl_drop_thresh, attn_common.h "attention-
 probability dropout RNG").  The hash is a pure function, so the masks of a finished forward can be recomputed here in numpy
 uint64 / uint32 arithmetic from the per-site seeds the engine recorded (engine.Run / LayerSave) and handed to the CPU oracle
 (oracle.dropout_masks) -- a train-mode comparison with the oracle then sees a dropout site applied at the wrong place, with the
@@ -21,25 +21,27 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-_C1 = np.uint64(0x9E3779B97F4A7C15)
-_C2 = np.uint64(0xD6E8FEB86659FD93)
-_S32 = np.uint64(32)
-
-
 def fbl_hash(seed: int, idx: np.ndarray) -> np.ndarray:
-    """fbl_common.h:76-84 fbl_hash: two rounds of a 64 -> 32 bit multiply-xorshift mixer (uint64 wrap-around)."""
+    """fbl_common.h fbl_hash: index * odd constant, seed folded in by XOR, two multiply-xorshift rounds (uint32 wrap-around)"""
+    idx = idx.astype(np.uint64)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        x = idx.astype(np.uint64) * _C1 + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
-        x ^= x >> _S32
-        x *= _C2
-        x ^= x >> _S32
-        x *= _C2
-        x ^= x >> _S32
-    return (x & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        h = lo * np.uint32(0x9E3779B1)
+        h ^= s_lo
+        h ^= (hi << np.uint32(13)) | (hi >> np.uint32(19))
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x7FEB352D)
+        h ^= h >> np.uint32(15)
+        h ^= s_hi
+        h *= np.uint32(0x846CA68B)
+        h ^= h >> np.uint32(16)
+    return h
 
 
 def drop_thresh(p: float) -> int:
-    """fbl_common.h:97-103 fbl_drop_thresh: p (a float) -> 32-bit threshold, drop iff hash < thresh"""
+    """fbl_common.h fbl_drop_thresh: p (a float) -> 32-bit threshold, drop iff hash < thresh"""
     t = float(np.float32(p)) * 4294967296.0
     return int(min(max(t, 0.0), 4294967295.0))
 

@@ -63,6 +63,38 @@ def test_gemm_plain_bias(L, M, N, K):
         assert (o32[:, N:] == 7.0).all(), "wrote outside N"
 
 
+@pytest.mark.parametrize("M,N,K", [(8512, 192, 1536), (4100, 192, 1536), (2050, 96, 1536), (5000, 176, 1536), (9024, 16, 1536), (3000, 192, 192),
+                                   (2049, 48, 1536)])
+def test_gemm_tall_and_narrow_strided_views(L, M, N, K):
+    """Tall-and-narrow launches (the adapter backward's dz = (dy . Wu) (*) gate, autograd of model/adapter.py:38-42): plain and
+    gated (AUX_MUL_POS_BF16) epilogues, strided operand / aux / output views as the engine passes them (dy and dz are column
+    blocks of one [N, 1792] buffer), row counts that are not a multiple of the tile height, column counts that leave the last tile
+    column partly empty; nothing outside the output's columns is written."""
+    A_full = bf(rnd(M, K + 256, seed=1)).to(BF16)
+    A = A_full[:, :K]  # lda = K + 256
+    B = bf(rnd(N, K, seed=2, scale=0.05)).to(BF16)
+    base = A.float() @ B.float().t()
+    out_full = torch.full((M, N + 40), 3.0, dtype=BF16, device=DEV)
+    out = out_full[:, 8:8 + N]
+    L.gemm(A, B, out_bf16=out, N=N)
+    close(out, base, 1e-2, 1e-2, "narrow plain")
+    assert (out_full[:, :8] == 3.0).all() and (out_full[:, 8 + N:] == 3.0).all(), "wrote outside the output columns"
+    z_full = bf(rnd(M, N + 16, seed=4)).to(BF16)
+    z = z_full[:, :N]
+    out_full.fill_(3.0)
+    L.gemm(A, B, alpha=1.0 / 0.9, aux=z, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=out, N=N)
+    close(out, base / 0.9 * (z.float() > 0), 1e-2, 1e-2, "narrow gated")
+    assert (out_full[:, :8] == 3.0).all() and (out_full[:, 8 + N:] == 3.0).all()
+    # an asymmetric operand pins the orientation: A = [I | 0] picks the first columns of B
+    if K <= M:
+        A2 = torch.zeros(M, K, dtype=BF16, device=DEV)
+        A2[:K] = torch.eye(K, dtype=BF16, device=DEV)
+        Bi = (torch.arange(N * K, device=DEV).view(N, K) % 251).to(BF16)
+        o2 = torch.empty(M, N, dtype=BF16, device=DEV)
+        L.gemm(A2, Bi, out_bf16=o2)
+        assert torch.equal(o2[:K].float(), Bi.float().t()) and (o2[K:] == 0).all()
+
+
 def test_gemm_asymmetric_identity(L):
     """A = I catches transposed C writes (guide rule: always test with an asymmetric B)."""
     K = 128

@@ -26,3 +26,4 @@ for rep in range(2):
     print(f"ln_fwd full   {timeit(lambda: L.ln_fwd(y=y, p_drop=0.1, seed=5, r_plain=r, gamma=g, beta=b, eps=1e-7, out_t=t, out_stats=st, out_bf16=ob, N=N, H=H)):7.1f} us")
     print(f"ln_fwd stats  {timeit(lambda: L.ln_fwd(y=t, gamma=g, beta=b, eps=1e-7, out_stats=st, out_bf16=ob, N=N, H=H)):7.1f} us")
     print(f"ln_bwd (+fold){timeit(lambda: L.ln_bwd(dout, t, st, g, p_drop=0.1, seed=5, out_dt=dt, out_dy_bf16=dyb, dgamma=dg, dbeta=db, dysum=dys, ws=ws)):7.1f} us")
+    print(f"ln_bwd p=0    {timeit(lambda: L.ln_bwd(dout, t, st, g, p_drop=0.0, seed=0, out_dt=dt, out_dy_bf16=dyb, dgamma=dg, dbeta=db, dysum=dys, ws=ws)):7.1f} us   (no mask regeneration: what the hash costs)")

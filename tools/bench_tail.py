@@ -35,3 +35,5 @@ print(f"pair  {timeit(both):7.1f} us")
 dy = torch.randn(M, H, device=dev).to(torch.bfloat16); upT = Wu.t().contiguous(); dz = torch.empty(M, A, dtype=torch.bfloat16, device=dev)
 dzf = lambda: L.gemm(dy, upT, alpha=1.1, aux=z, aux_kind=L.AUX_MUL_POS_BF16, out_bf16=dz, N=A)
 print(f"dz    {timeit(dzf):7.1f} us")
+tail0 = lambda: L.adapter_up_resid_fwd(z, Wu, bu, x, t, p_drop=0.0, seed=0, r_norm=(rt, st, g, b, None))
+print(f"tail p=0 {timeit(tail0):7.1f} us   (no dropout: what the hash costs)")
