@@ -32,9 +32,10 @@ def _relidx_range(S, cfg):
     return _RANGE[key]
 
 
-def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
-    """defer_pos=True: skip the position-table GEMMs and return the state `pos_table_grads` needs (the caller runs it
-    off the critical path); otherwise dpqk [span2, 2H] (bf16, [dPQ|dPK]) is filled here."""
+def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
+    """defer_pos=True: skip the position-table GEMMs and return the state they need (the engine runs them for ALL layer
+    executions at once at the end of backward: pos_table_grads_batched); otherwise dpqk [span2, 2H] (bf16, [dPQ|dPK]) is filled
+    here.  bufs: optional pre-allocated (G1T, G2T, QT, KT) -- one execution's slices of the engine's per-step tensors."""
     B, S, H, nh, span2 = run.B, run.S, eng.H, eng.nh, eng.span2
     Sp = (S + 63) // 64 * 64
     dev = eng.dev
@@ -51,8 +52,11 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     # One launch prepares the backward: K^T, Q^T (head-major), PK^T, PQ^T and D_i = dO_i . O_i.  (Folding D into kernel A
     # was measured: +43 us there for the O tiles on its critical path; five separate small launches: 65 us in situ.)
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
-    KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
-    QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+    if bufs is not None:
+        G1T, G2T, QT, KT = bufs
+    else:
+        KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+        QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0)
@@ -66,8 +70,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False):
     L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
                          B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
-    G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
-    G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+    if bufs is None:
+        G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+        G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
     if POISON_GT:  # test switch: blocks the shear kernel legitimately leaves unwritten must never be read
         G1T.fill_(float("nan"))
         G2T.fill_(float("nan"))
@@ -106,3 +111,50 @@ def pos_table_grads(eng, st, ws):
     L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
     L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
     return dpos
+
+
+def pos_chain_buffers(eng, run, n_exec):
+    """Per-step tensors that receive, execution by execution, what the position-table products of ALL layer executions need:
+    G1^T / G2^T (k-blocked, written by the shear passes) and Q^T / K^T (written by the preparation kernel).  One allocation each,
+    [n_exec, nh, ...]: execution e is slice e, and (execution, head) is ONE strided batch dimension for the GEMMs at the end."""
+    B, S, nh = run.B, run.S, eng.nh
+    Sp = (S + 63) // 64 * 64
+    rmin, rcnt = _relidx_range(S, eng.cfg)
+    blk = B * (Sp // 32) * rcnt * 32
+    dev = eng.dev
+    return dict(G1T=torch.empty(n_exec, nh, blk, dtype=BF16, device=dev), G2T=torch.empty(n_exec, nh, blk, dtype=BF16, device=dev),
+                QT=torch.empty(n_exec, nh, 64, B, Sp, dtype=BF16, device=dev), KT=torch.empty(n_exec, nh, 64, B, Sp, dtype=BF16, device=dev),
+                rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, n=0, seeds=[], cap=n_exec)
+
+
+def pos_table_grads_batched(eng, run, pc):
+    """The relative-position-table gradient of the whole backward pass in five launches at its END (it feeds only
+    encoder.LayerNorm's gamma / beta, the last thing backward needs): until round 4 every layer execution ran its own chain
+    (two split-K products, folds, cast, projection, dropout, accumulation) on a side stream next to the following layer's GEMMs
+    -- 9.3 ms of side-queue kernel time per step whose long-lived workgroups cost the main stream 2.7 ms.  Now, over all E
+    executions at once (a strided batch of E*nh problems each):
+        dPK[e,h] = G1^T[e,h] . Q^T[e,h]^T ,  dPQ[e,h] = G2^T[e,h] . K^T[e,h]^T     (k-steps beyond a sample's length skipped)
+        dR_e     = [dPQ | dPK]_e . [Wq ; Wk]_e                                       (one batched GEMM against the packed weights)
+        dR       = sum_e dropout_e(dR_e)                                             (fbl_dropout_sum_f32: each through its own mask)
+    Returns dR [span2, H] fp32.  autograd of model/deberta.py:779, 847-853, 870-918 summed over the executions."""
+    H, nh, span2 = eng.H, eng.nh, eng.span2
+    E, rmin, rcnt, B, Sp = pc["n"], pc["rmin"], pc["rcnt"], pc["B"], pc["Sp"]
+    dev = eng.dev
+    Kc = B * Sp
+    kblk = rcnt * 32
+    ks = dict(kskip_len=run.klen, kskip_steps=Sp // 64) if getattr(run, "klen", None) is not None else {}
+    dpb = torch.zeros(E, span2, 2 * H, dtype=BF16, device=dev)  # [dPQ | dPK] of every execution, bf16 operand of the projection
+    for key_g, key_t, col0 in (("G1T", "QT", H), ("G2T", "KT", 0)):
+        G = pc[key_g][:E].view(E * nh, -1)
+        a = torch.as_strided(G, (E * nh, rcnt, 32), (G.stride(0), 32, 1))
+        T = pc[key_t][:E].view(E * nh, 64, Kc)
+        d = torch.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
+        # two K slices (the skipping path is the accumulating one), folded deterministically through the workspace
+        L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, **ks)
+        # [e, h, r, 64] -> rows rmin.. of [e, r, h*64 + .] (fp32 -> bf16): one strided copy per table
+        dpb[:, rmin:rmin + rcnt, col0:col0 + H].view(E, rcnt, nh, 64).copy_(d.view(E, nh, rcnt, 64).permute(0, 2, 1, 3))
+    tmp = torch.empty(E, span2, H, dtype=F32, device=dev)
+    L.gemm(dpb, eng.WposT_exec[:E], out_f32=tmp)
+    dR = torch.empty(span2, H, dtype=F32, device=dev)
+    L.dropout_sum_f32(tmp, pc["seeds"][:E] if run.p_hid > 0 else [0] * E, run.p_hid, dR)
+    return dR

@@ -22,6 +22,9 @@ namespace {
 //   small: 128x128, 4 waves (2x2), MI=4  -> 69.6 KiB LDS, 2 workgroups/CU   (narrow / short GEMMs)
 //   big:   256x256, 8 waves (2x4), MI=8  -> 136 KiB LDS, 1 workgroup/CU     (1/3 fewer LDS bytes per MFMA)
 // (the large square-ish problems run the 8-phase kernel of gemm8.hip instead of the NW = 8 configuration)
+constexpr int KSKIP_MAX_STEPS = 2048;  // K-steps per split of a launch that skips zero blocks (LDS list of the valid ones)
+constexpr int KSKIP_SMEM_BYTES = 3 * (128 * BK * 2 + 64 * BK * 2) + KSKIP_MAX_STEPS * 2 + 16;
+
 template <int NW> struct TileCfg {
   static constexpr int BM = 32 * NW, BN = 32 * NW;
   static constexpr int TILE_BYTES = BM * BK * 2;
@@ -171,37 +174,67 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
     __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
   } else if constexpr (KSKIP) {
     // K-steps whose operand block is known to be all zero (rows beyond a sample's last valid position in the G^T
-    // operand of the position-table gradients) are neither fetched nor multiplied
-    auto next_valid = [&](int kt) {
-      while (kt < kt1) {
-        const int b = kt / g.kskip_steps;
-        if ((kt - b * g.kskip_steps) * BK < g.kskip_len[b]) break;
-        ++kt;
-      }
-      return kt;
-    };
-    int kt = next_valid(kt0);
-    if (kt < kt1) {
-      issue(kt, 0);
-      __syncthreads();
-      int stage = 0;
-      while (kt < kt1) {
-        const int nxt = next_valid(kt + 1);
-        if (nxt < kt1) issue(nxt, stage ^ 1);
-        const char* base = smem + stage * STAGE_BYTES;
-        if (n0 + wn * 64 < g.N) {  // (N = 64 here: the second column of waves only helps with the staging)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            bf16x8 af[MI], bfg[4];
-            read_frags(base, s, af, bfg);
-            mfma_block(af, bfg);
-          }
+    // operand of the position-table gradients) are neither fetched nor multiplied.  The problem is a pure stream -- 332 x 64
+    // outputs against megabytes of G^T per (layer execution, head), N = 64 -- so what matters is how many bytes a workgroup
+    // keeps in flight: the valid K-steps are listed ONCE (wave 0, ballot compaction into LDS: no scalar table lookup in
+    // front of every request) and run through a ring of three 24 KiB stages (A 128 rows, B 64 rows: the clamped duplicate
+    // rows of a 128-row B image are not fetched) with counted vmcnt and one raw barrier per step, as in the SCHED 5 ring:
+    // two steps of operands in flight instead of one fetched behind a drained queue (round 4: 2-stage loop, __syncthreads
+    // per step, a dependent scalar load + division per step: 3.3 us per K-step).
+    constexpr int KS_STAGE = Cfg::TILE_BYTES + 64 * BK * 2;  // 16 KiB + 8 KiB
+    constexpr int KS_NS = 3;
+    int16_t* klist = (int16_t*)(smem + KS_NS * KS_STAGE);    // up to KSKIP_MAX_STEPS entries (host-checked)
+    int* kcount = (int*)(smem + KS_NS * KS_STAGE + KSKIP_MAX_STEPS * 2);
+    if (wave == 0) {
+      int cnt = 0;
+      for (int base = kt0; base < kt1; base += 64) {
+        const int kt = base + lane;
+        bool valid = false;
+        if (kt < kt1) {
+          const int b = kt / g.kskip_steps;
+          valid = (kt - b * g.kskip_steps) * BK < g.kskip_len[b];
         }
-        __syncthreads();
-        kt = nxt;
-        stage ^= 1;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+        if (valid) klist[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int16_t)kt;
+        cnt += __builtin_popcountll(m);
       }
+      if (lane == 0) *kcount = cnt;
     }
+    __syncthreads();
+    const int nv = __builtin_amdgcn_readfirstlane(*kcount);
+    auto issue_ks = [&](int i, int slot) {
+      const int kt = __builtin_amdgcn_readfirstlane((int)klist[i]);
+      char* base = smem + slot * KS_STAGE;
+      const long koff = (long)kt * BK;
+      const long koff_a = g.a_kblk ? (long)kt * 2 * g.a_kblk : koff;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int off = (q * NW + wave) * 1024;
+        glds16(a_src[q] + koff_a, base + off);
+        if ((q * NW + wave) * 8 < 64) glds16(b_src[q] + koff, base + Cfg::TILE_BYTES + off);  // (q < 2: six requests per thread)
+      }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < KS_NS - 1; ++s_)
+      if (s_ < nv) issue_ks(s_, s_);
+    for (int i = 0; i < nv; ++i) {
+      if (i + 1 < nv) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (i + KS_NS - 1 < nv) issue_ks(i + KS_NS - 1, (i + KS_NS - 1) % KS_NS);
+      const char* base = smem + (i % KS_NS) * KS_STAGE;
+      if (n0 + wn * 64 < g.N) {  // (N = 64 here: the second column of waves only helps with the staging)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 af[MI], bfg[4];
+          read_frags(base, s, af, bfg);
+          mfma_block(af, bfg);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of the stage are complete
+    }
+    __builtin_amdgcn_s_barrier();  // all LDS tile reads retired before the epilogue reuses the memory
   } else {
   issue(kt0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
@@ -682,7 +715,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   if (accumulate && kskip_len) {
     static bool attr_ks = false;
     auto kfn = gemm_bf16_nt_kernel<4, FBL_ACT_NONE, FBL_AUX_NONE, true, 0, 4, true>;
-    constexpr int smem_bytes = TileCfg<4>::SMEM_BYTES;
+    constexpr int smem_bytes = KSKIP_SMEM_BYTES > TileCfg<4>::SMEM_BYTES ? KSKIP_SMEM_BYTES : TileCfg<4>::SMEM_BYTES;
+    if (N > 64 || (K / BK + splitk - 1) / splitk > KSKIP_MAX_STEPS) return FBL_ERR_SHAPE;  // (64 B rows staged, LDS list of valid K-steps)
     if (!attr_ks) {
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
       if (e != hipSuccess) return (int)e;

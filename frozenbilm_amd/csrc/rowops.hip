@@ -785,6 +785,32 @@ __global__ void dropout_bf16_kernel(bf16* x, float p, uint64_t seed0, const uint
     x[i] = f2bf(bf2f(x[i]) * fbl_dropout_scale(seed, (uint64_t)i, thr, ik));
 }
 
+// out[i] = sum_s dropout_{seed_s}(x[s][i]): the per-layer-execution gradients of the shared relative-position table, each
+// through the mask its forward drew (model/deberta.py:779 pos_dropout), folded into one tensor in slice order (deterministic)
+struct DropSumArgs {
+  uint64_t seeds[FBL_DROPSUM_MAX_SLICES];
+  const float* x;
+  const uint64_t* seed_dev;
+  float* out;
+  long n;
+  int ns;
+  float p;
+};
+__global__ void dropout_sum_kernel(DropSumArgs a) {
+  const uint32_t thr = fbl_drop_thresh(a.p);
+  const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const uint64_t word = (a.p > 0.f && a.seed_dev) ? *a.seed_dev : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < a.ns; ++s) {
+      float v = a.x[(long)s * a.n + i];
+      if (a.p > 0.f) v *= fbl_dropout_scale(a.seeds[s] + word, (uint64_t)i, thr, ik);
+      acc += v;
+    }
+    a.out[i] = acc;
+  }
+}
+
 inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
   long b = (n + block - 1) / block;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -805,7 +831,7 @@ inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
     default: return FBL_ERR_SHAPE;                                                                   \
   }
 
-extern "C" int fbl_abi_version(void) { return 5; }
+extern "C" int fbl_abi_version(void) { return 6; }
 
 extern "C" int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
                                 float* out_t, void* stream) {
@@ -1067,6 +1093,17 @@ extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, con
   if (n <= 0) return 0;
   hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, p_drop, seed, seed_dev, out_f32,
                      (bf16*)out_bf16, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_dropout_sum_f32(const float* x, int64_t n, int n_slices, const uint64_t* seeds, float p_drop,
+                                   const uint64_t* seed_dev, float* out_f32, void* stream) {
+  if (n <= 0) return 0;
+  if (n_slices < 1 || n_slices > FBL_DROPSUM_MAX_SLICES || !x || !out_f32 || (p_drop > 0.f && !seeds) || p_drop >= 1.f) return FBL_ERR_ARG;
+  DropSumArgs a{};
+  for (int s = 0; s < n_slices; ++s) a.seeds[s] = (p_drop > 0.f) ? seeds[s] : 0;
+  a.x = x; a.seed_dev = seed_dev; a.out = out_f32; a.n = (long)n; a.ns = n_slices; a.p = p_drop;
+  hipLaunchKernelGGL(dropout_sum_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -88,7 +88,7 @@ class Engine:
         L.load()
         self.dev = dev
         self.opts = dict(getattr(model, "engine_options", None) or {})
-        unknown = set(self.opts) - {"eager_logits", "side_stream", "pos_on_main", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group"}
+        unknown = set(self.opts) - {"eager_logits", "side_stream", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group"}
         if unknown:
             raise ValueError(f"unknown engine_options: {sorted(unknown)}")
         self._build_flat()
@@ -117,7 +117,7 @@ class Engine:
         # Engine options: `model.engine_options` (a dict read ONCE, when the engine is built; the product reads no environment
         # variable).  Defaults are the shipped configuration; the other values exist for A/B measurements (tools/, tests):
         #   eager_logits   fill the full [N, V] logits in every forward even when only the loss is consumed (reference-eager)
-        #   side_stream    False = single-stream execution;  pos_on_main: position-table gradient chain on the main stream
+        #   side_stream    False = single-stream execution (the per-step composition of the merged adapter rows otherwise runs beside the forward)
         #   fold_dx        adapter dx folded into the dense dX GEMM;  dw_on_side: generic dW route on the side stream
         #   fuse_tail      adapter up-projection + block dropout + residual as one epilogue (fbl_adapter_up_resid_fwd)
         #   merge          dense layer + adapter down-projection as one GEMM;  dw_group: adapter gradient products per launch
@@ -126,7 +126,6 @@ class Engine:
         self.side_ws = torch.empty(8 << 20, dtype=F32, device=dev)
         self.side_cs_ws = L.colsum_ws(max(self.H, self.I), dev)
         self.use_side_stream = bool(o.get("side_stream", True))
-        self.pos_on_main = bool(o.get("pos_on_main", False))
         self.fold_dx = bool(o.get("fold_dx", True))
         self.dw_on_side = bool(o.get("dw_on_side", False))
         self.fuse_tail = bool(o.get("fuse_tail", True))
@@ -257,6 +256,12 @@ class Engine:
                 self.bd16_rev[j, 0].copy_(d["bd"])
                 d["WdM"], d["bdM"] = self.WdM_rev[j], self.bdM_rev[j]
             self.Lw.append(d)
+        # [Wq ; Wk]^T of every layer EXECUTION that has a backward, in backward order (the last layer's two enhanced-mask-decoder
+        # passes, then layers nL-2 .. 0): the position-table gradients of all of them are projected by one strided-batch GEMM
+        order = [nL - 1, nL - 1] + list(range(nL - 2, -1, -1))
+        self.WposT_exec = torch.empty(len(order), H, 2 * H, dtype=BF16, device=dev)
+        for e, li in enumerate(order):
+            self.WposT_exec[e].copy_(self.Lw[li]["WqkvT"][:, : 2 * H])
         if self.cfg.conv_kernel_size:
             w = P["deberta.encoder.conv.conv.weight"]  # [H_out, H_in, 3] -> [H_out, k*H_in + c]
             W2 = w.permute(0, 2, 1).reshape(H, 3 * H)
@@ -1101,10 +1106,7 @@ class Engine:
             if "a1" in ad:
                 do = self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1)
             L.gemm(do, W["WoT"], out_bf16=dctx)
-        dqkv, pst = self._attn_bwd(run, sv, dctx)
-        # position tables (off the critical path, side stream): dR += dropout_bwd([dPQ|dPK] . [Wq;Wk]), accumulated over
-        # all layer executions; only encoder.LayerNorm's gamma/beta consume it, at the very end of backward
-        self._pos_grad_async(run, sv, pst, W)
+        dqkv = self._attn_bwd(run, sv, dctx)
         if not sv.emd:
             dx = torch.empty(N, H, dtype=F32, device=dev)
             L.gemm(dqkv, W["WqkvT"], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dx)
@@ -1117,42 +1119,6 @@ class Engine:
         L.gemm(dqkv[:, :H], W["WqkvT"][:, :H], aux=dt1, aux_kind=L.AUX_ADD_F32, out_f32=dq)
         return dq, dqkv[:, H:]
 
-    def _pos_grad_async(self, run, sv, pst, W):
-        from .attn_bwd import pos_table_grads
-
-        H = self.H
-        if "deberta.encoder.LayerNorm.weight" not in self.G:  # ft_ln=False: nothing trainable sits behind the position tables
-            return
-
-        def work(ws):
-            dpos = pos_table_grads(self, pst, ws)
-            dpb = torch.empty(self.span2, 2 * H, dtype=BF16, device=self.dev)
-            L.cast_bf16(dpos, dpb)
-            if run.p_hid > 0:
-                tmp = torch.empty(self.span2, H, dtype=F32, device=self.dev)
-                L.gemm(dpb, W["WqkvT"][:, : 2 * H], out_f32=tmp)
-                L.dropout_f32(tmp, run.p_hid, sv.seed_pos, out_f32=tmp)
-                run.dR.add_(tmp)
-            else:
-                L.gemm(dpb, W["WqkvT"][:, : 2 * H], aux=run.dR, aux_kind=L.AUX_ADD_F32, out_f32=run.dR)
-
-        if self.use_side_stream and not self.pos_on_main:
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                work(self.side_ws)
-            if not torch.cuda.is_current_stream_capturing():
-                for k in ("G1T", "G2T", "QT", "KT"):
-                    pst[k].record_stream(self.side)
-            else:
-                # Inside a capture the graph's private pool hands a block that Python has released to the next main-stream
-                # allocation of its size -- the K^T / Q^T / G^T of the NEXT layer execution, ~0.7 ms of main-stream work
-                # later -- with no edge from this chain's side-stream reads to that writer: the four operands of every
-                # chain stay referenced for the life of the captured step (390 MB per layer execution, 9.7 GB per graph).
-                run.__dict__.setdefault("_pos_keep", []).extend(pst[k] for k in ("G1T", "G2T", "QT", "KT"))
-            run.side_used = True
-        else:
-            work(self.sk_ws)
-
     def _attn_bwd(self, run, sv, dctx):
         B, S, H, nh = run.B, run.S, self.H, self.nh
         N = run.N
@@ -1162,8 +1128,19 @@ class Engine:
         if self.reducer is not None:  # ~0.35 ms without one-workgroup-per-CU GEMM tiles: where gradient collectives may start
             self.reducer.window()
 
-        pst = disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True)
-        return dqkv, pst
+        # The position-table products of this execution (dPK = G1^T.Q, dPQ = G2^T.K) are NOT formed here: the shear passes and
+        # the preparation kernel write their operands into this execution's slice of per-step tensors, and one strided-batch
+        # chain at the END of backward handles all executions (attn_bwd.pos_table_grads_batched).  ft_ln=False: nothing
+        # trainable sits behind the position tables, the operands are scratch.
+        pc = getattr(run, "pos_chain", None)
+        bufs = None
+        if pc is not None:
+            e = pc["n"]
+            bufs = (pc["G1T"][e], pc["G2T"][e], pc["QT"][e], pc["KT"][e])
+            pc["seeds"].append(sv.seed_pos)
+            pc["n"] = e + 1
+        disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True, bufs=bufs)
+        return dqkv
 
     def _head_bwd(self, run, rows, dlog, dq, all_rows=False):
         """Backward of the prediction head for the rows `rows` (int32 indices into the N token rows) given their bf16
@@ -1245,7 +1222,11 @@ class Engine:
             self._dw_flush(run, red)
 
         stage_done("head")
-        run.dR = torch.zeros(self.span2, H, dtype=F32, device=dev)
+        run.pos_chain = None
+        if "deberta.encoder.LayerNorm.weight" in self.G:
+            from .attn_bwd import pos_chain_buffers
+
+            run.pos_chain = pos_chain_buffers(self, run, len(run.layers))
         # ---- EMD: two executions of the last layer, newest first
         layers = run.layers
         dkv_ops = []
@@ -1286,8 +1267,12 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self.side)  # all adapter dW/db are in the flat grad buffer
         # ---- relative-position LayerNorm (receives grads from every layer execution)
         rn = run.rel_norm
-        if "deberta.encoder.LayerNorm.weight" in self.G:
-            L.ln_bwd(run.dR, rn.t, rn.stats, rn.gamma, dgamma=self.G.get("deberta.encoder.LayerNorm.weight"),
+        if run.pos_chain is not None:
+            from .attn_bwd import pos_table_grads_batched
+
+            dR = pos_table_grads_batched(self, run, run.pos_chain)
+            run.pos_chain = None
+            L.ln_bwd(dR, rn.t, rn.stats, rn.gamma, dgamma=self.G.get("deberta.encoder.LayerNorm.weight"),
                      dbeta=self.G.get("deberta.encoder.LayerNorm.bias"), ws=self._ln_ws)
         if red:
             red.ready("relln")

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
+ABI_VERSION = 6  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "fbl_cast_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
     "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
+    "fbl_dropout_sum_f32": (_i, [_vp, _l, _i, _vp, _f, _vp, _vp, _vp]),
 }
 
 _LIB = None
@@ -626,6 +627,15 @@ def dropout_f32(x, p_drop, seed, out_f32=None, out_bf16=None):
     assert x.is_contiguous()
     _chk(load().fbl_dropout_f32(_p(x), float(p_drop), int(seed), _seed_dev(), _p(out_f32), _p(out_bf16), x.numel(), _stream()),
          "fbl_dropout_f32")
+
+
+def dropout_sum_f32(x, seeds, p_drop, out):
+    """out[i] = sum_s dropout_{seeds[s]}(x[s, i]); x: [n_slices, ...] fp32 contiguous, out: one slice's shape"""
+    ns = x.shape[0]
+    n = x.numel() // ns
+    assert x.is_contiguous() and out.is_contiguous() and out.numel() == n and len(seeds) == ns
+    arr = (C.c_uint64 * ns)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
+    _chk(load().fbl_dropout_sum_f32(_p(x), n, ns, arr, float(p_drop), _seed_dev(), _p(out), _stream()), "fbl_dropout_sum_f32")
 
 
 def dropout_bf16_(x, p_drop, seed):

