@@ -845,31 +845,37 @@ def measure_cpu_baseline_cfg1():
     except Exception:
         phys = os.cpu_count()
     prev = torch.get_num_threads()
-    torch.set_num_threads(int(phys))
+    cfg = BO.BertOracleConfig()  # BertConfig() defaults: 12 layers, H=768, 12 heads, I=3072, vocab 30522; features_dim 768
+    P = BO.synth_params(cfg, seed=0, std=0.02)
+    g = torch.Generator().manual_seed(1)
+    Bc, T, Lt = 4, 10, 64
+    video = torch.randn(Bc, T, cfg.features_dim, generator=g)
+    ids = torch.randint(1000, cfg.vocab_size, (Bc, Lt), generator=g)
+    am, vm = torch.ones(Bc, Lt, dtype=torch.long), torch.ones(Bc, T, dtype=torch.long)
+    runs = {}
     try:
-        cfg = BO.BertOracleConfig()  # BertConfig() defaults: 12 layers, H=768, 12 heads, I=3072, vocab 30522; features_dim 768
-        P = BO.synth_params(cfg, seed=0, std=0.02)
-        g = torch.Generator().manual_seed(1)
-        Bc, T, Lt = 4, 10, 64
-        video = torch.randn(Bc, T, cfg.features_dim, generator=g)
-        ids = torch.randint(1000, cfg.vocab_size, (Bc, Lt), generator=g)
-        am, vm = torch.ones(Bc, Lt, dtype=torch.long), torch.ones(Bc, T, dtype=torch.long)
-        times = []
-        with torch.no_grad():
-            for i in range(7):
-                t = time.time()
-                out = BO.forward(cfg, P, ids, am, video, vm)
-                assert out["logits"].shape == (Bc, T + Lt, cfg.vocab_size)
-                if i >= 2:
-                    times.append(time.time() - t)
-        dt = sum(times) / len(times)
+        # a 0.1 s forward does not scale to 128 cores (and the box is shared: see loadavg): timed with all physical cores AND
+        # with 16 threads, the faster one is reported -- `cores` says which
+        for nthr in sorted({int(phys), min(int(phys), 16)}, reverse=True):
+            torch.set_num_threads(nthr)
+            times = []
+            with torch.no_grad():
+                for i in range(7):
+                    t = time.time()
+                    out = BO.forward(cfg, P, ids, am, video, vm)
+                    assert out["logits"].shape == (Bc, T + Lt, cfg.vocab_size)
+                    if i >= 2:
+                        times.append(time.time() - t)
+            runs[nthr] = sum(times) / len(times)
     finally:
         torch.set_num_threads(prev)
+    phys, dt = min(runs.items(), key=lambda kv: kv[1])
     return {"value": Bc / dt, "unit": "samples/s", "cores": int(phys), "kind": "port", "loadavg": os.getloadavg()[0],
             "logical_cpus": os.cpu_count(), "ms_per_forward": dt * 1e3,
             "sample": f"BASELINE configs[0]: BERT-base (12L, H=768, vocab 30522) + linear_video, B={Bc}, T=10x768, L={Lt} (S={T + Lt}), MLM "
-                      f"forward through the fp32 CPU oracle (oracle/bert_oracle.py): 2 warm-up + {len(times)} timed iterations, torch "
-                      f"threads={int(phys)} (physical cores); survey container (8 vCPU): 27.8 samples/s"}
+                      f"forward through the fp32 CPU oracle (oracle/bert_oracle.py): 2 warm-up + {len(times)} timed iterations per thread "
+                      f"count, ms per forward by torch threads: {({k: round(v * 1e3, 1) for k, v in runs.items()})}, reported: "
+                      f"{int(phys)} threads; survey container (8 vCPU): 27.8 samples/s"}
 
 
 if __name__ == "__main__":

@@ -143,7 +143,9 @@ def pos_table_grads_batched(eng, run, pc):
     Kc = B * Sp
     kblk = rcnt * 32
     ks = dict(kskip_len=run.klen, kskip_steps=Sp // 64) if getattr(run, "klen", None) is not None else {}
-    dpb = torch.zeros(E, span2, 2 * H, dtype=BF16, device=dev)  # [dPQ | dPK] of every execution, bf16 operand of the projection
+    # [dPQ | dPK] of every execution, rows rmin .. rmin + rcnt of the tables (the others cannot be touched: their gradient is
+    # zero): bf16 operand of the projection, fully written by the two copies below
+    dpb = torch.empty(E, rcnt, 2 * H, dtype=BF16, device=dev)
     for key_g, key_t, col0 in (("G1T", "QT", H), ("G2T", "KT", 0)):
         G = pc[key_g][:E].view(E * nh, -1)
         a = torch.as_strided(G, (E * nh, rcnt, 32), (G.stride(0), 32, 1))
@@ -151,10 +153,11 @@ def pos_table_grads_batched(eng, run, pc):
         d = torch.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
         # two K slices (the skipping path is the accumulating one), folded deterministically through the workspace
         L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, **ks)
-        # [e, h, r, 64] -> rows rmin.. of [e, r, h*64 + .] (fp32 -> bf16): one strided copy per table
-        dpb[:, rmin:rmin + rcnt, col0:col0 + H].view(E, rcnt, nh, 64).copy_(d.view(E, nh, rcnt, 64).permute(0, 2, 1, 3))
-    tmp = torch.empty(E, span2, H, dtype=F32, device=dev)
+        # [e, h, r, 64] -> [e, r, h*64 + .] (fp32 -> bf16): one strided copy per table
+        dpb[:, :, col0:col0 + H].view(E, rcnt, nh, 64).copy_(d.view(E, nh, rcnt, 64).permute(0, 2, 1, 3))
+    tmp = torch.empty(E, rcnt, H, dtype=F32, device=dev)
     L.gemm(dpb, eng.WposT_exec[:E], out_f32=tmp)
-    dR = torch.empty(span2, H, dtype=F32, device=dev)
-    L.dropout_sum_f32(tmp, pc["seeds"][:E] if run.p_hid > 0 else [0] * E, run.p_hid, dR)
+    dR = torch.zeros(span2, H, dtype=F32, device=dev)
+    # (dropout keys of the [span2, H] table: element (r, c) <-> r*H + c)
+    L.dropout_sum_f32(tmp, pc["seeds"][:E] if run.p_hid > 0 else [0] * E, run.p_hid, dR[rmin:rmin + rcnt], key0=rmin * H)
     return dR

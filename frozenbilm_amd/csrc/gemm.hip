@@ -56,11 +56,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
   const int wm = wave / WC, wn = wave % WC;
 
   int tm, tn;
-  tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
+  int by = blockIdx.y;
+  if constexpr (KSKIP) {
+    // The batched position-table products are a 2-D grid (few tiles x many (batch, K-slice) pairs): consecutive workgroups
+    // -- x fastest -- go round-robin to the 8 XCDs, which would put the row tiles of ONE pair on different XCDs, each
+    // fetching that pair's B operand (Q^T / K^T, 1.3 MB) into its own L2.  Re-deal: 8 pairs at a time, workgroup L of the
+    // group of 8 * tiles on XCD L % 8 takes pair L % 8, tile L / 8 -- all tiles of a pair share one L2.
+    const int gx = gridDim.x;
+    if ((gridDim.y & 7) == 0) {
+      const int lin = blockIdx.y * gx + blockIdx.x;
+      const int grp = lin / (8 * gx), r = lin - grp * 8 * gx;
+      by = grp * 8 + (r & 7);
+      tile_of_block(r >> 3, g.tiles_m, g.tiles_n, &tm, &tn);
+    } else {
+      tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
+    }
+  } else {
+    tile_of_block(blockIdx.x, g.tiles_m, g.tiles_n, &tm, &tn);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int batch = blockIdx.y / g.splitk;
-  const int ks = blockIdx.y % g.splitk;
+  const int batch = by / g.splitk;
+  const int ks = by % g.splitk;
   const int nk_total = g.K / BK;
   const int per = (nk_total + g.splitk - 1) / g.splitk;
   const int kt0 = ks * per;

@@ -346,7 +346,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
       for (int r = 0; r < 4; ++r) v[r] = (a4[r] * g.alpha + bv[r]) * rs;
       if (SPLITK) {
         if (g.ws) {  // plain 16-byte stores of the partial tile; folded into out_f32 by splitk_reduce_kernel
-          *(f32x4*)(g.ws + (((long)blockIdx.y * g.M + m) * g.Nw + n4)) = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(g.ws + (((long)(batch * g.splitk + ks) * g.M + m) * g.Nw + n4)) = (f32x4){v[0], v[1], v[2], v[3]};
         } else {
           for (int r = 0; r < 4; ++r)
             if (n4 + r < g.N) unsafeAtomicAdd(g.out_f32 + cbase + (long)m * g.ldc + n4 + r, v[r]);

@@ -792,7 +792,7 @@ struct DropSumArgs {
   const float* x;
   const uint64_t* seed_dev;
   float* out;
-  long n;
+  long n, key0;
   int ns;
   float p;
 };
@@ -804,7 +804,7 @@ __global__ void dropout_sum_kernel(DropSumArgs a) {
     float acc = 0.f;
     for (int s = 0; s < a.ns; ++s) {
       float v = a.x[(long)s * a.n + i];
-      if (a.p > 0.f) v *= fbl_dropout_scale(a.seeds[s] + word, (uint64_t)i, thr, ik);
+      if (a.p > 0.f) v *= fbl_dropout_scale(a.seeds[s] + word, (uint64_t)(a.key0 + i), thr, ik);
       acc += v;
     }
     a.out[i] = acc;
@@ -1096,13 +1096,13 @@ extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, con
   FBL_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int fbl_dropout_sum_f32(const float* x, int64_t n, int n_slices, const uint64_t* seeds, float p_drop,
+extern "C" int fbl_dropout_sum_f32(const float* x, int64_t n, int64_t key0, int n_slices, const uint64_t* seeds, float p_drop,
                                    const uint64_t* seed_dev, float* out_f32, void* stream) {
   if (n <= 0) return 0;
-  if (n_slices < 1 || n_slices > FBL_DROPSUM_MAX_SLICES || !x || !out_f32 || (p_drop > 0.f && !seeds) || p_drop >= 1.f) return FBL_ERR_ARG;
+  if (n_slices < 1 || n_slices > FBL_DROPSUM_MAX_SLICES || !x || !out_f32 || (p_drop > 0.f && !seeds) || p_drop >= 1.f || key0 < 0) return FBL_ERR_ARG;
   DropSumArgs a{};
   for (int s = 0; s < n_slices; ++s) a.seeds[s] = (p_drop > 0.f) ? seeds[s] : 0;
-  a.x = x; a.seed_dev = seed_dev; a.out = out_f32; a.n = (long)n; a.ns = n_slices; a.p = p_drop;
+  a.x = x; a.seed_dev = seed_dev; a.out = out_f32; a.n = (long)n; a.key0 = (long)key0; a.ns = n_slices; a.p = p_drop;
   hipLaunchKernelGGL(dropout_sum_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;

@@ -98,6 +98,7 @@ class Engine:
         self._no_pos_cache = False  # set while an inference graph is captured: a replay must not depend on state kept outside it
         self.reducer = None  # set by parallel.GradReducer for data-parallel training
         self._pad_bufs = {}
+        self._dyz_pool: Dict[tuple, list] = {}  # [N, K_fold] operands of the folded adapter backward with their padding zeroed once
         self.params_version = 0  # bumped by FusedAdam.step (which updates the flat buffer through raw pointers)
         self._ops_version = None
         self.skip_dead_layer = True
@@ -982,7 +983,7 @@ class Engine:
             return dt, dyb, dt_full
         return dt, dyb
 
-    def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed, dz_out=None):
+    def _adapter_bwd(self, run, ent, dyb, z, xin_b, seed, dz_out=None, pooled=None):
         """Backward of _adapter_fwd.  dyb: grad of the adapter output (bf16 [N,H]); returns grad of its input (bf16).
         dz_out: the caller folds dx = dy + dz.Wd into the next GEMM ([dy | dz] operand, _layer_bwd): dz is written there
         (a column slice of that operand), no dx is formed and None is returned."""
@@ -1009,7 +1010,7 @@ class Engine:
             # (fbl_adapter_bwd_dw: every tile walks all rows, no split-K round trip) on the MAIN stream -- its workgroups live
             # for the whole pass, and a resident side-stream workgroup keeps the one-per-CU tiles of the big GEMMs off its CU.
             # (up.bias's gradient colsum(dy) comes out of ln_bwd.)
-            run.dw_pending.append((A, nm, (dyb, z, dz, xin_b), run.dw_count))
+            run.dw_pending.append((A, nm, (dyb, z, dz, xin_b), run.dw_count, pooled))
             run.dw_count += 1
             return dx
 
@@ -1046,7 +1047,7 @@ class Engine:
         while pend and (force or len({rec[1] for rec in pend}) >= self.dw_group):
             take, names, rest = {}, set(), []
             for rec in pend:
-                A, nm, seg, _ = rec
+                A, nm, seg = rec[:3]
                 if nm in names or len(names) >= min(self.dw_group, L.ADW_MAX_ADAPTERS):
                     rest.append(rec)
                 else:
@@ -1055,6 +1056,10 @@ class Engine:
             for A, recs in take.items():
                 L.adapter_bwd_dw([([seg], self.G[nm + ".up.weight"], self.G[nm + ".down.weight"], self.G[nm + ".down.bias"])
                                   for nm, seg in recs], A=A)
+            kept = {id(r) for r in rest}
+            for rec in pend:  # [dy | dz | 0] operands whose last reader has now been enqueued go back to the pool (same stream)
+                if id(rec) not in kept and rec[4] is not None:
+                    self._dyz_pool.setdefault(tuple(rec[4].shape), []).append(rec[4])
             pend[:] = rest
         if red is not None:  # a finished stage is final once none of ITS adapters has a parked product left (any order: the
             # repeated last layer waits one launch longer than the layers behind it, and must not hold their buckets back)
@@ -1092,12 +1097,24 @@ class Engine:
             # write the two column blocks of ONE operand and the dense dX GEMM runs with K = H + A (+ zero padding) -- the
             # K = A GEMM that formed dx, its 26 MB output and its re-read are gone (25 us per layer execution)
             A1 = ad["a1"]["A"]
-            dyz = torch.empty(N, self.Kf1, dtype=BF16, device=dev)
-            if self.Kf1 > H + A1:
-                dyz[:, H + A1:].zero_()  # finite values under the zero weight columns
+            # The K padding columns only have to hold finite values (their weight columns are zero): buffers come from a small
+            # pool whose padding was zeroed ONCE -- nobody writes those columns -- instead of a strided fill per layer execution
+            # (25 launches a step).  A buffer returns to the pool when the parked gradient products that read its [dy | dz]
+            # blocks have been enqueued (_dw_flush).  Captured steps and the immediate-launch route allocate as before.
+            pooled = None
+            can_pool = (not torch.cuda.is_current_stream_capturing() and ad["a1"]["Ap"] <= 256 and H % 8 == 0 and not self.dw_on_side)
+            free = self._dyz_pool.get((N, self.Kf1)) if can_pool else None
+            if free:
+                dyz = pooled = free.pop()
+            elif can_pool:
+                dyz = pooled = torch.zeros(N, self.Kf1, dtype=BF16, device=dev)
+            else:
+                dyz = torch.empty(N, self.Kf1, dtype=BF16, device=dev)
+                if self.Kf1 > H + A1:
+                    dyz[:, H + A1:].zero_()  # finite values under the zero weight columns
             dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,
                                     dysum=self.G[ad["a1"]["name"] + ".up.bias"], dy_out=dyz[:, :H])
-            self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1, dz_out=dyz[:, H:H + A1])
+            self._adapter_bwd(run, ad["a1"], dy1, sv.z1, sv.ob, sv.seed_ad1, dz_out=dyz[:, H:H + A1], pooled=pooled)
             L.gemm(dyz, W["WoF"], out_bf16=dctx)
         else:
             dt1, dy1 = self._ln_bwd(p + ".attention.output.LayerNorm", da, sv.ln1, run.p_hid, sv.seed_ln1,

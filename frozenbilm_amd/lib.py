@@ -69,7 +69,7 @@ SIGNATURES = {
     "fbl_cast_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
     "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
-    "fbl_dropout_sum_f32": (_i, [_vp, _l, _i, _vp, _f, _vp, _vp, _vp]),
+    "fbl_dropout_sum_f32": (_i, [_vp, _l, _l, _i, _vp, _f, _vp, _vp, _vp]),
 }
 
 _LIB = None
@@ -629,13 +629,14 @@ def dropout_f32(x, p_drop, seed, out_f32=None, out_bf16=None):
          "fbl_dropout_f32")
 
 
-def dropout_sum_f32(x, seeds, p_drop, out):
-    """out[i] = sum_s dropout_{seeds[s]}(x[s, i]); x: [n_slices, ...] fp32 contiguous, out: one slice's shape"""
+def dropout_sum_f32(x, seeds, p_drop, out, key0=0):
+    """out[i] = sum_s dropout_{seeds[s]}(x[s, i]), element i keyed by key0 + i; x: [n_slices, ...] fp32 contiguous, out: one
+    slice's shape (contiguous)"""
     ns = x.shape[0]
     n = x.numel() // ns
     assert x.is_contiguous() and out.is_contiguous() and out.numel() == n and len(seeds) == ns
     arr = (C.c_uint64 * ns)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
-    _chk(load().fbl_dropout_sum_f32(_p(x), n, ns, arr, float(p_drop), _seed_dev(), _p(out), _stream()), "fbl_dropout_sum_f32")
+    _chk(load().fbl_dropout_sum_f32(_p(x), n, int(key0), ns, arr, float(p_drop), _seed_dev(), _p(out), _stream()), "fbl_dropout_sum_f32")
 
 
 def dropout_bf16_(x, p_drop, seed):

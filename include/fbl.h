@@ -329,14 +329,15 @@ int fbl_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, const uint64_t* seed_dev, float* out_f32, void* out_bf16, int64_t n,
                     void* stream);
 int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64_t* seed_dev, int64_t n, void* stream);
-/* out[i] = sum over the n_slices slices s of dropout_{seeds[s]}(x[s*n + i]) (element i of every slice keyed by (seeds[s], i) like
- * fbl_dropout_f32; p_drop == 0: plain sum), slices added in index order.  `seeds` is a HOST array of n_slices <=
+/* out[i] = sum over the n_slices slices s of dropout_{seeds[s]}(x[s*n + i]) (element i of every slice keyed by (seeds[s], key0 + i):
+ * the keys of fbl_dropout_f32 on a tensor of which the slice is the part starting at element key0; p_drop == 0: plain sum),
+ * slices added in index order.  `seeds` is a HOST array of n_slices <=
  * FBL_DROPSUM_MAX_SLICES values (copied into the launch).  The gradients of the shared relative-position table of all layer
  * executions, each through the mask its forward drew, folded in one pass.  ref: autograd of model/deberta.py:779 (pos_dropout)
  * summed over the 24 + 2 executions that share `rel_embeddings` (:507-575, :1382-1412). */
 #define FBL_DROPSUM_MAX_SLICES 64
-int fbl_dropout_sum_f32(const float* x, int64_t n, int n_slices, const uint64_t* seeds, float p_drop, const uint64_t* seed_dev,
-                        float* out_f32, void* stream);
+int fbl_dropout_sum_f32(const float* x, int64_t n, int64_t key0, int n_slices, const uint64_t* seeds, float p_drop,
+                        const uint64_t* seed_dev, float* out_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,13 @@ def test_dropout_sum_over_slices(L):
     out2 = torch.empty_like(out)
     L.dropout_sum_f32(x, [(s_ + 987654321) & 0xFFFFFFFFFFFFFFFF for s_ in seeds], 0.1, out2)
     assert torch.equal(out, out2)
+    # a slice that starts at element key0 of the keyed tensor
+    k0 = 96 * 37
+    full = torch.empty(n, dtype=F32, device=DEV)
+    L.dropout_sum_f32(x, seeds, 0.1, full)
+    part = torch.empty(n - k0, dtype=F32, device=DEV)
+    L.dropout_sum_f32(x[:, k0:].contiguous(), seeds, 0.1, part, key0=k0)
+    assert torch.equal(part, full[k0:])
 
 
 def test_gemm_asymmetric_identity(L):

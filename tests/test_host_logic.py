@@ -147,14 +147,14 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
     nL = 8
     names = lambda li: [f"layer.{li}.a1", f"layer.{li}.a2"]
     G = {n + sfx: n for li in range(nL) for n in names(li) for sfx in (".up.weight", ".down.weight", ".down.bias")}
-    eng = types.SimpleNamespace(dw_group=6, G=G, _bucket_key=lambda n: "layer" + n.split(".")[1])
+    eng = types.SimpleNamespace(dw_group=6, G=G, _bucket_key=lambda n: "layer" + n.split(".")[1], _dyz_pool={})
     run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0)
     ready = []
     red = types.SimpleNamespace(ready=ready.append)
 
     def park(li):
         for n in names(li):
-            run.dw_pending.append((192, n, (None, None, None, None), run.dw_count))
+            run.dw_pending.append((192, n, (None, None, None, None), run.dw_count, None))
             run.dw_count += 1
 
     def stage_done(key):
