@@ -150,14 +150,14 @@ def pos_table_grads_batched(eng, run, pc):
         G = pc[key_g][:E].view(E * nh, -1)
         a = torch.as_strided(G, (E * nh, rcnt, 32), (G.stride(0), 32, 1))
         T = pc[key_t][:E].view(E * nh, 64, Kc)
-        d = torch.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
+        d = L.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
         # two K slices (the skipping path is the accumulating one), folded deterministically through the workspace
         L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, **ks)
-        # [e, h, r, 64] -> [e, r, h*64 + .] (fp32 -> bf16): one strided copy per table
-        dpb[:, :, col0:col0 + H].view(E, rcnt, nh, 64).copy_(d.view(E, nh, rcnt, 64).permute(0, 2, 1, 3))
+        # [e, h, r, 64] fp32 -> [e, r, h*64 + .] bf16, into this table's column block
+        L.heads_to_rows_bf16(d.view(E, nh, rcnt, 64), dpb[:, :, col0:col0 + H])
     tmp = torch.empty(E, rcnt, H, dtype=F32, device=dev)
     L.gemm(dpb, eng.WposT_exec[:E], out_f32=tmp)
-    dR = torch.zeros(span2, H, dtype=F32, device=dev)
+    dR = L.zeros(span2, H, dtype=F32, device=dev)
     # (dropout keys of the [span2, H] table: element (r, c) <-> r*H + c)
     L.dropout_sum_f32(tmp, pc["seeds"][:E] if run.p_hid > 0 else [0] * E, run.p_hid, dR[rmin:rmin + rcnt], key0=rmin * H)
     return dR

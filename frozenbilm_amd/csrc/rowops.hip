@@ -811,6 +811,23 @@ __global__ void dropout_sum_kernel(DropSumArgs a) {
   }
 }
 
+// dst[e][r][h*64 + c] (bf16, row stride ld_dst) = src[e][h][r][c] (fp32): the per-head position-table gradients of every layer
+// execution -> the [rows, heads*64] operand layout of the projection GEMM; 8 lanes per 64-float head row (2 x 16-byte loads)
+__global__ void heads_to_rows_bf16_kernel(const float* src, bf16* dst, int E, int nh, int rows, long ld_dst) {
+  const long total = (long)E * nh * rows * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(t & 7);
+    const long q = t >> 3;  // (e, h, r)
+    const int r = (int)(q % rows);
+    const long eh = q / rows;
+    const int h = (int)(eh % nh);
+    const long e = eh / nh;
+    const f32x4 a = *(const f32x4*)(src + q * 64 + c8 * 8), b = *(const f32x4*)(src + q * 64 + c8 * 8 + 4);
+    *(bf16x8*)(dst + (e * rows + r) * ld_dst + h * 64 + c8 * 8) =
+        (bf16x8){f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  }
+}
+
 inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
   long b = (n + block - 1) / block;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -1093,6 +1110,21 @@ extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, con
   if (n <= 0) return 0;
   hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, p_drop, seed, seed_dev, out_f32,
                      (bf16*)out_bf16, (long)n);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int fbl_zero(void* p, int64_t bytes, void* stream) {
+  if (bytes <= 0) return 0;
+  if (!p) return FBL_ERR_ARG;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
+}
+extern "C" int fbl_heads_to_rows_bf16(const float* src, void* dst_bf16, int E, int nh, int rows, int64_t ld_dst, void* stream) {
+  if (E <= 0 || nh <= 0 || rows <= 0) return 0;
+  if (!src || !dst_bf16 || ld_dst < (int64_t)nh * 64 || (ld_dst % 8)) return FBL_ERR_ARG;
+  if (((uintptr_t)dst_bf16 & 15) || ((uintptr_t)src & 15)) return FBL_ERR_ALIGN;
+  hipLaunchKernelGGL(heads_to_rows_bf16_kernel, dim3(grid1d((long)E * nh * rows * 8)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16*)dst_bf16, E, nh, rows, (long)ld_dst);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -189,7 +189,7 @@ class Engine:
         """Make p.grad the views of the flat grad buffer; zero it when the user dropped the grads (set_to_none)."""
         fresh = all(self.named[n].grad is None for n in self.order)
         if fresh:
-            self.flat_grad.zero_()
+            L.zero_(self.flat_grad)
         for n in self.order:
             p = self.named[n]
             if p.grad is None:
@@ -872,7 +872,7 @@ class Engine:
             rows = run.rows
             run.rows_i32 = rows.to(torch.int32)
             R = rows.numel()
-            run.loss_acc = torch.zeros(2, dtype=F32, device=dev)
+            run.loss_acc = L.zeros(2, dtype=F32, device=dev)
             if R > 0:
                 if loss_rows:
                     hrows = hl.bf16  # the head already ran on exactly these rows
@@ -1170,7 +1170,7 @@ class Engine:
         else:
             tableT = torch.zeros(H, Vp, dtype=BF16, device=dev)
             tableT[:, :Vout] = self.Ansb.t()
-        dhl = torch.zeros(R, H, dtype=F32, device=dev)
+        dhl = L.zeros(R, H, dtype=F32, device=dev)
         if R >= 2048:  # enough rows to fill the chip without splitting K
             L.gemm(dlog, tableT, out_f32=dhl)
         else:  # few rows, long K -> split-K so the grid covers the chip (accumulates into zeros)
@@ -1209,7 +1209,7 @@ class Engine:
 
         red = _Ready(self, run, reducer) if reducer is not None else None
         run.dw_pending, run.dw_ready_keys, run.dw_count = [], [], 0
-        dq = torch.zeros(N, H, dtype=F32, device=dev)
+        dq = L.zeros(N, H, dtype=F32, device=dev)
         Vout = run.Vout
         Vp = _ru(Vout, 64)
         # ---- CE + head, on the labelled rows only (all other rows have exactly zero gradient)

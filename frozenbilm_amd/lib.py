@@ -70,6 +70,8 @@ SIGNATURES = {
     "fbl_dropout_f32": (_i, [_vp, _f, _u64, _vp, _vp, _vp, _l, _vp]),
     "fbl_dropout_bf16": (_i, [_vp, _f, _u64, _vp, _l, _vp]),
     "fbl_dropout_sum_f32": (_i, [_vp, _l, _l, _i, _vp, _f, _vp, _vp, _vp]),
+    "fbl_zero": (_i, [_vp, _l, _vp]),
+    "fbl_heads_to_rows_bf16": (_i, [_vp, _vp, _i, _i, _i, _l, _vp]),
 }
 
 _LIB = None
@@ -627,6 +629,27 @@ def dropout_f32(x, p_drop, seed, out_f32=None, out_bf16=None):
     assert x.is_contiguous()
     _chk(load().fbl_dropout_f32(_p(x), float(p_drop), int(seed), _seed_dev(), _p(out_f32), _p(out_bf16), x.numel(), _stream()),
          "fbl_dropout_f32")
+
+
+def zero_(t):
+    """t[...] = 0 on the current stream through the library (contiguous tensors only); returns t"""
+    assert t.is_contiguous()
+    _chk(load().fbl_zero(_p(t), t.numel() * t.element_size(), _stream()), "fbl_zero")
+    return t
+
+
+def zeros(*shape, dtype, device):
+    return zero_(torch.empty(*shape, dtype=dtype, device=device))
+
+
+def heads_to_rows_bf16(src, dst):
+    """dst[e, r, h*64 + c] = src[e, h, r, c]; src fp32 [E, nh, rows, 64] contiguous, dst bf16 [E, rows, >= nh*64] (column view ok)"""
+    E, nh, rows, c = src.shape
+    assert c == 64 and src.is_contiguous() and dst.shape[0] == E and dst.shape[1] == rows and dst.stride(2) == 1
+    assert dst.stride(0) == rows * dst.stride(1)
+    _req(src, torch.float32, "src")
+    _req(dst, torch.bfloat16, "dst")
+    _chk(load().fbl_heads_to_rows_bf16(_p(src), _p(dst), E, nh, rows, dst.stride(1), _stream()), "fbl_heads_to_rows_bf16")
 
 
 def dropout_sum_f32(x, seeds, p_drop, out, key0=0):

@@ -30,7 +30,9 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         eng = self.model._engine
         if eng is not None and not set_to_none:
-            eng.flat_grad.zero_()
+            from . import lib as L
+
+            L.zero_(eng.flat_grad)
             return
         super().zero_grad(set_to_none=set_to_none)
 

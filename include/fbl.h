@@ -336,6 +336,12 @@ int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64
  * executions, each through the mask its forward drew, folded in one pass.  ref: autograd of model/deberta.py:779 (pos_dropout)
  * summed over the 24 + 2 executions that share `rel_embeddings` (:507-575, :1382-1412). */
 #define FBL_DROPSUM_MAX_SLICES 64
+/* p[0 .. bytes) = 0 on `stream` (hipMemsetAsync): the zero fills of the step (gradient accumulators, split-K targets) */
+int fbl_zero(void* p, int64_t bytes, void* stream);
+/* dst[e][r][h*64 + c] (bf16, row stride ld_dst elements, ld_dst >= nh*64) = src[e][h][r][c] (fp32, contiguous [E][nh][rows][64]):
+ * per-head results of a strided-batch GEMM -> the [rows, heads*64] operand of the next one (position-table gradients,
+ * autograd of model/deberta.py:847-853).  16-byte aligned pointers, ld_dst % 8 == 0. */
+int fbl_heads_to_rows_bf16(const float* src, void* dst_bf16, int E, int nh, int rows, int64_t ld_dst, void* stream);
 int fbl_dropout_sum_f32(const float* x, int64_t n, int64_t key0, int n_slices, const uint64_t* seeds, float p_drop,
                         const uint64_t* seed_dev, float* out_f32, void* stream);
 

@@ -131,6 +131,20 @@ def test_dropout_sum_over_slices(L):
     assert torch.equal(part, full[k0:])
 
 
+def test_heads_to_rows_and_zero(L):
+    """fbl_heads_to_rows_bf16 ([E, nh, rows, 64] fp32 -> column block of [E, rows, 2*nh*64] bf16) and fbl_zero"""
+    E, nh, rows = 3, 5, 37
+    src = rnd(E, nh, rows, 64, seed=4)
+    dst = torch.full((E, rows, 2 * nh * 64), 9.0, dtype=BF16, device=DEV)
+    L.heads_to_rows_bf16(src, dst[:, :, nh * 64:])
+    ref = src.permute(0, 2, 1, 3).reshape(E, rows, nh * 64).to(BF16)
+    assert torch.equal(dst[:, :, nh * 64:], ref) and (dst[:, :, : nh * 64] == 9.0).all()
+    t = torch.full((1000, 33), 5.0, device=DEV)
+    assert L.zero_(t) is t and (t == 0).all()
+    z = L.zeros(7, 3, dtype=BF16, device=DEV)
+    assert z.shape == (7, 3) and (z == 0).all()
+
+
 def test_gemm_asymmetric_identity(L):
     """A = I catches transposed C writes (guide rule: always test with an asymmetric B)."""
     K = 128
