@@ -15,4 +15,6 @@ timeout 900 bash tools/pmc_bench.sh $T/traffic > gpurun_out/$T/traffic.txt 2>&1
 rm -rf gpurun_out/$T/traffic/FETCH_SIZE gpurun_out/$T/traffic/WRITE_SIZE
 timeout 900 bash tools/pmc_step.sh $T/pmc > gpurun_out/$T/pmc.txt 2>&1
 rm -rf gpurun_out/$T/pmc/s1 gpurun_out/$T/pmc/s2
+timeout 300 python bench.py --workload videoqa --steps 10 --warmup 3 > gpurun_out/$T/bench_videoqa.json 2>/dev/null
+timeout 300 python bench.py --workload mc --steps 10 --warmup 3 > gpurun_out/$T/bench_mc.json 2>/dev/null
 head -30 gpurun_out/$T/q1.txt; tail -3 gpurun_out/$T/traffic.txt; head -20 gpurun_out/$T/pmc.txt; cut -c1-250 gpurun_out/$T/bench_final.json
