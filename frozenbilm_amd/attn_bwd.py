@@ -32,6 +32,24 @@ def _relidx_range(S, cfg):
     return _RANGE[key]
 
 
+def gt_tilemasks(eng, run):
+    """(mask of G1^T, mask of G2^T) for this pass -- a function of the lengths and the relative-index map only, so one pair
+    serves every layer execution: the shear passes skip the zero fill of the G^T rows outside the marked 128-row tiles and the
+    position-table products skip fetching them (include/fbl.h fbl_gt_tilemask)."""
+    m = getattr(run, "_gt_masks", None)
+    if m is None:
+        B, S = run.B, run.S
+        Sp = (S + 63) // 64 * 64
+        rmin, rcnt = _relidx_range(S, eng.cfg)
+        klen = getattr(run, "klen", None)
+        m = tuple(L.gt_tilemask(eng.relidx(S), klen, B, S, Sp, eng.span2, neg, rmin, rcnt) for neg in (0, 1))
+        try:
+            run._gt_masks = m
+        except AttributeError:
+            pass
+    return m
+
+
 def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     """defer_pos=True: skip the position-table GEMMs and return the state they need (the engine runs them for ALL layer
     executions at once at the end of backward: pos_table_grads_batched); otherwise dpqk [span2, 2H] (bf16, [dPQ|dPK]) is filled
@@ -76,12 +94,14 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     if POISON_GT:  # test switch: blocks the shear kernel legitimately leaves unwritten must never be read
         G1T.fill_(float("nan"))
         G2T.fill_(float("nan"))
+    # (without klen the products read every row of G^T: everything outside the windows must then be zero-filled)
+    m1, m2 = gt_tilemasks(eng, run) if klen is not None else (None, None)
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
-                            lin=lin, border=border, row0=row0)
+                            lin=lin, border=border, row0=row0, tilemask=m1)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
-                            rcnt=rcnt, lin=lin, border=border, row0=row0)
+                            rcnt=rcnt, lin=lin, border=border, row0=row0, tilemask=m2)
     del dS, dST
-    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen)
+    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen, masks=(m1, m2))
     if defer_pos:
         return state
     dpos = pos_table_grads(eng, state, getattr(eng, "sk_ws", None))
@@ -108,8 +128,9 @@ def pos_table_grads(eng, st, ws):
     # G^T blocks beyond a sample's last valid position are all zero: the shear kernel does not write them and the GEMM
     # skips those k-steps (roughly half of K on ragged batches)
     ks = dict(kskip_len=st["klen"], kskip_steps=Sp // 64) if st.get("klen") is not None else {}
-    L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
-    L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, **ks)
+    m1, m2 = st.get("masks", (None, None)) if ks else (None, None)
+    L.gemm(a1, QT.view(nh, 64, Kc), out_f32=o_pk, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, kskip_tilemask=m1, **ks)
+    L.gemm(a2, KT.view(nh, 64, Kc), out_f32=o_pq, splitk=sk, ws=ws, K=Kc, a_kblock=kblk, kskip_tilemask=m2, **ks)
     return dpos
 
 
@@ -146,13 +167,14 @@ def pos_table_grads_batched(eng, run, pc):
     # [dPQ | dPK] of every execution, rows rmin .. rmin + rcnt of the tables (the others cannot be touched: their gradient is
     # zero): bf16 operand of the projection, fully written by the two copies below
     dpb = torch.empty(E, rcnt, 2 * H, dtype=BF16, device=dev)
-    for key_g, key_t, col0 in (("G1T", "QT", H), ("G2T", "KT", 0)):
+    masks = gt_tilemasks(eng, run) if ks else (None, None)
+    for (key_g, key_t, col0), tmask in zip((("G1T", "QT", H), ("G2T", "KT", 0)), masks):
         G = pc[key_g][:E].view(E * nh, -1)
         a = torch.as_strided(G, (E * nh, rcnt, 32), (G.stride(0), 32, 1))
         T = pc[key_t][:E].view(E * nh, 64, Kc)
         d = L.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
         # two K slices (the skipping path is the accumulating one), folded deterministically through the workspace
-        L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, **ks)
+        L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, kskip_tilemask=tmask, **ks)
         # [e, h, r, 64] fp32 -> [e, r, h*64 + .] bf16, into this table's column block
         L.heads_to_rows_bf16(d.view(E, nh, rcnt, 64), dpb[:, :, col0:col0 + H])
     tmp = torch.empty(E, rcnt, H, dtype=F32, device=dev)

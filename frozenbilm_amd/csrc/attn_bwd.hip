@@ -480,7 +480,38 @@ struct ShearArgs {
   int rmin, rcnt;                         // only rows [rmin, rmin+rcnt) of G^T can be non-zero (range of relidx)
   int lin;                                // |delta| < lin: idx(delta) is injective (identity buckets) -> plain stores
   const int32_t* row0;                    // [B+1] packed-row layout of `out` (PACKED kernels; see attn_fwd.hip) or null
+  const uint32_t* tilemask;               // [B][Sp/64] (fbl_gt_tilemask) or null: bit t set <=> rows [128t, 128t+128) of the rcnt
+                                          // G^T rows can be non-zero in this 64-row k-step; other rows are NOT written (nor read)
 };
+// rows [rbase, rbase + nks*32) of the position tables that the 32 output rows r0.. of a sample with kl valid positions reach
+__device__ __forceinline__ void gt_window(const int16_t* relidx, int S, int kl, int r0, bool neg, int Wg, int* rbase, int* nks) {
+  const int hi = 2 * S - 2;
+  const int dlo = neg ? -(r0 + 31) : r0 - (kl - 1);
+  const int dhi = neg ? (kl - 1 - r0) : (r0 + 31);
+  const int rb = (int)relidx[min(max(dlo + S - 1, 0), hi)] & ~7;
+  const int rt = (int)relidx[min(max(dhi + S - 1, 0), hi)];
+  *rbase = rb;
+  *nks = min((rt - rb + 32) / 32, Wg / 32);
+}
+// one thread per (sample, 64-row k-step): which 128-row tiles of the rcnt G^T rows the step's two 32-row blocks can touch
+__global__ void gt_tilemask_kernel(const int16_t* relidx, const int32_t* klen, int B, int S, int Sp, int neg, int rmin, int rcnt,
+                                   int Wg, uint32_t* mask) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int steps = Sp / 64;
+  if (t >= B * steps) return;
+  const int b = t / steps, j = t - b * steps;
+  const int kl = klen ? min(klen[b], S) : S;
+  uint32_t m = 0;
+  for (int half = 0; half < 2; ++half) {
+    const int r0 = (2 * j + half) * 32;
+    if (r0 >= kl) continue;
+    int rbase, nks;
+    gt_window(relidx, S, kl, r0, neg != 0, Wg, &rbase, &nks);
+    const int lo = max(rbase - rmin, 0), hi = min(rbase + nks * 32 - rmin, rcnt);
+    for (int tt = lo / 128; tt * 128 < hi; ++tt) m |= 1u << tt;
+  }
+  mask[t] = m;
+}
 constexpr int C_IDX = 0;           // int16[1024]: relative-index table padded to the tile grid
 constexpr int C_G = C_IDX + 2048;  // [32][Wg + 8] bf16
 
@@ -515,8 +546,12 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
     // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
     // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
-    if ((bx & 1) && (r0 - 32 < kl))
-      if (!(FBL_ATTN_DBGBITS & 64)) for (int id = tid; id < a.rcnt * 4; id += 128) *(bf16x8*)(gt + (long)id * 8) = z8;
+    if ((bx & 1) && (r0 - 32 < kl)) {
+      const uint32_t tm = a.tilemask ? a.tilemask[b * (Sp / 64) + (bx >> 1)] : ~0u;
+      if (!(FBL_ATTN_DBGBITS & 64))
+        for (int id = tid; id < a.rcnt * 4; id += 128)
+          if ((tm >> (id >> 9)) & 1) *(bf16x8*)(gt + (long)id * 8) = z8;  // (id >> 2 = row, 128 rows per tile)
+    }
     if (row < lim) {
       bf16* op = a.out + (rb + row) * a.ldout + h * 64 + g * 4;
 #pragma unroll
@@ -524,23 +559,23 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     }
     return;
   }
-  // table rows reachable from these 32 rows x the valid columns [0, kl): [rbase, rtop]; rbase aligned down to 8 so the
+  // table rows reachable from these 32 rows x the valid columns [0, kl): [rbase, rbase + nks*32); rbase aligned down to 8 so the
   // PT fragments stay 16-byte aligned.  dS is only defined (and non-zero) inside [kl x kl].
-  const int dlo = NEG ? -(r0 + 31) : r0 - (kl - 1);
-  const int dhi = NEG ? (kl - 1 - r0) : (r0 + 31);
-  const int rbase = (int)a.relidx[clampi(dlo + S - 1, 0, hi)] & ~7;
-  const int rtop = (int)a.relidx[clampi(dhi + S - 1, 0, hi)];
-  const int nks = min((rtop - rbase + 32) / 32, a.Wg / 32);
+  int rbase, nks;
+  gt_window(a.relidx, S, kl, r0, NEG, a.Wg, &rbase, &nks);
+  (void)hi;
   const int izero = (int)a.relidx[S - 1];  // idx(0)
   {
     const int vpr = nks * 4;  // 16-byte vectors per row
     for (int t = tid; t < 32 * vpr; t += 128) *(bf16x8*)(G + (t / vpr) * LDG + (t % vpr) * 8) = z8;
   }
   attn::load_idx_padded(idx, a.relidx, S, Sp, tid, 128);
-  // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here
+  // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here -- only inside the 128-row tiles that the
+  // consumer fetches for this 64-row k-step (tilemask: the tiles either of its two blocks can touch)
+  const uint32_t tmask = a.tilemask ? a.tilemask[b * (Sp / 64) + (bx >> 1)] : ~0u;
   for (int id = tid; id < a.rcnt * 4; id += 128) {
     const int r = a.rmin + (id >> 2);
-    if (!(FBL_ATTN_DBGBITS & 64) && (r < rbase || r >= rbase + nks * 32)) *(bf16x8*)(gt + (long)id * 8) = z8;
+    if (!(FBL_ATTN_DBGBITS & 64) && ((tmask >> (id >> 9)) & 1) && (r < rbase || r >= rbase + nks * 32)) *(bf16x8*)(gt + (long)id * 8) = z8;
   }
   const long xbase = (((long)b * a.nh + h) * Sp + row) * Sp;
   f32x4 acc[4];
@@ -668,6 +703,12 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
 
 }  // namespace
 
+static inline int shear_wg(int S, int span2) {  // columns of the shear pass's G tile (a multiple of 32)
+  int Wg = S + 31 + 7;
+  if (Wg > span2) Wg = span2;
+  return (Wg + 31) / 32 * 32;
+}
+
 extern "C" int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh,
                                void* stream) {
   if (ld % 8) return FBL_ERR_ALIGN;
@@ -720,18 +761,16 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
                                          int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen,
                                          const int32_t* border, void* out, int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
-                                         int Sp, int nh, int span2, const int32_t* row0, void* stream) {
+                                         int Sp, int nh, int span2, const int32_t* row0, const uint32_t* gt_tilemask, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32) return FBL_ERR_SHAPE;
   if ((ldout % 4) || (y_sd % 8) || (y_sb % 8) || (y_sh % 8)) return FBL_ERR_ALIGN;
   if (B <= 0 || nh <= 0) return 0;
   // index range reachable from 32 consecutive rows: <= S + 31 entries (idx has slope <= 1), +7 for the 8-alignment
-  int Wg = S + 31 + 7;
-  if (Wg > span2) Wg = span2;
-  Wg = (Wg + 31) / 32 * 32;
+  const int Wg = shear_wg(S, span2);
   if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
   if (row0 && !klen) return FBL_ERR_ARG;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, border, (bf16*)out, ldout, (bf16*)GT,
-              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span, row0};
+              B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span, row0, gt_tilemask};
   attn_debug_init();
   const int smem_bytes = C_G + 32 * (Wg + 8) * 2;
   static int attr_bytes = 0;
@@ -755,6 +794,18 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
     hipLaunchKernelGGL(attn_bwd_shear_kernel<true>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_gt_tilemask(const int16_t* relidx, const int32_t* klen, int B, int S, int Sp, int span2, int neg, int gt_rmin,
+                               int gt_rcnt, uint32_t* mask, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64 || span2 > 512 || span2 % 32 || !relidx || !mask) return FBL_ERR_SHAPE;
+  if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2 || gt_rcnt > 32 * 128) return FBL_ERR_ARG;
+  if (B <= 0) return 0;
+  const int n = B * (Sp / 64);
+  hipLaunchKernelGGL(gt_tilemask_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, relidx, klen, B, S, Sp, neg, gt_rmin,
+                     gt_rcnt, shear_wg(S, span2), mask);
   FBL_CHECK_LAUNCH();
   return 0;
 }

@@ -210,6 +210,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void gemm_bf16_nt_kernel(
         if (kt < kt1) {
           const int b = kt / g.kskip_steps;
           valid = (kt - b * g.kskip_steps) * BK < g.kskip_len[b];
+          // (the 128-row tile of A this workgroup owns is all zero -- and unwritten -- in k-steps whose mask bit is clear)
+          if (valid && g.kskip_tilemask) valid = (g.kskip_tilemask[kt] >> tm) & 1u;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
         if (valid) klist[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int16_t)kt;
@@ -476,7 +478,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
                         float p_drop, uint64_t drop_seed, void* stream, int seg_n = 0, void* seg_out = nullptr,
                         int64_t seg_ld = 0, int64_t drop_row0 = 0, void* aux_stream = nullptr,
-                        const TailArgs* tail = nullptr, const uint64_t* drop_seed_dev = nullptr) {
+                        const TailArgs* tail = nullptr, const uint64_t* drop_seed_dev = nullptr,
+                        const uint32_t* kskip_tilemask = nullptr) {
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   if ((aux_kind == FBL_AUX_ADAPTER_TAIL) != (tail != nullptr)) return FBL_ERR_ARG;
   if (K <= 0 || (K % BK) != 0) return FBL_ERR_SHAPE;           // K must be a multiple of 64 (callers zero-pad)
@@ -507,6 +510,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.a_kblk = a_kblock_stride;
   g.kskip_len = kskip_len;
   g.kskip_steps = kskip_steps;
+  g.kskip_tilemask = kskip_tilemask;
   g.drop_thresh = 0; g.drop_seed = drop_seed; g.drop_seed_dev = drop_seed_dev; g.drop_inv_keep = 1.f; g.drop_ld = ldc;
   g.seg_n = seg_n; g.seg_out = (bf16*)seg_out; g.seg_ld = seg_ld; g.drop_row0 = drop_row0;
   g.r_t = nullptr; g.ld_r = 0; g.r_stats = nullptr; g.r_gamma = nullptr; g.r_beta = nullptr; g.r_rowmask = nullptr;
@@ -533,6 +537,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     g.drop_inv_keep = 1.f / (1.f - p_drop);
   }
   if (kskip_len && (kskip_steps <= 0 || !accumulate)) return FBL_ERR_ARG;  // only the split-K (accumulating) path skips
+  if (kskip_tilemask && (!kskip_len || M > 32 * 128)) return FBL_ERR_ARG;
   // big tiles only where both dimensions fill them and the grid still covers the chip
   static const int force_small = FBL_ENV_INT("FBL_GEMM_SMALL", 0);
   const bool big = !force_small && !accumulate && (p_drop <= 0.f || seg_n > 0 || tail) && (seg_n <= 0 || (seg_n & 255) == 0) &&
@@ -781,11 +786,12 @@ extern "C" int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
                                 int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                                 int64_t strideAux, int64_t strideBias, int splitk, float* splitk_ws,
                                 int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len, int kskip_steps,
-                                void* stream, void* aux_stream) {
+                                const uint32_t* kskip_tilemask, void* stream, void* aux_stream) {
   if (aux_kind == FBL_AUX_ADAPTER_TAIL) return FBL_ERR_ARG;  // (has its own entry point: fbl_adapter_up_resid_fwd)
   return gemm_nt_impl(A, lda, B, ldb, M, N, K, bias, rowscale, alpha, act, aux_kind, aux, ld_aux, out_f32, out_bf16,
                       out_pre_bf16, ldc, batch, strideA, strideB, strideC, strideAux, strideBias, splitk, splitk_ws,
-                      splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream, 0, nullptr, 0, 0, aux_stream);
+                      splitk_ws_floats, a_kblock_stride, kskip_len, kskip_steps, 0.f, 0, stream, 0, nullptr, 0, 0, aux_stream,
+                      nullptr, nullptr, kskip_tilemask);
 }
 
 // z[M, A] = dropout(relu(x[M,K] . Wd[A,K]^T + bd)): the adapter's down-projection with ReLU AND dropout in the GEMM

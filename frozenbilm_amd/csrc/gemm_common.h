@@ -33,6 +33,7 @@ struct GemmArgs {
   int Nw;
   const int32_t* kskip_len;  // optional: K is made of samples of kskip_steps k-steps; step j of sample b is all zero when 64*j >= kskip_len[b]
   int kskip_steps;
+  const uint32_t* kskip_tilemask;  // optional, with kskip_len: per 64-wide k-step, bit t set <=> rows [128t, 128t+128) of A can be non-zero
   long a_kblk;  // 0: A rows are K-contiguous.  >0: A is stored in 32-wide k blocks: A[m][k] at m*lda + (k/32)*a_kblk + k%32
   // post-activation dropout of the epilogue (adapter bottleneck, model/adapter.py:39-41): element (m, n) is keyed by
   // (drop_seed, m*drop_ld + n) exactly like fbl_dropout_bf16 on the [M, drop_ld] output; drop_thresh == 0 -> off

@@ -25,7 +25,7 @@ _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "fbl_abi_version": (_i, []),
     "fbl_gemm_bf16_nt": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l,
-                              _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp, _vp]),
+                              _l, _l, _l, _i, _vp, _l, _l, _vp, _i, _vp, _vp, _vp]),
     "fbl_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _f, _u64, _vp, _vp, _l, _vp]),
     "fbl_dense_adapter_down_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _f, _u64, _vp, _vp, _l, _vp, _vp]),
     "fbl_adapter_up_resid_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _l, _f, _u64, _vp, _vp, _l, _vp, _vp, _vp, _vp,
@@ -58,7 +58,8 @@ SIGNATURES = {
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
-                                       _vp, _vp]),
+                                       _vp, _vp, _vp]),
+    "fbl_gt_tilemask": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fbl_gather_rows_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp]),
@@ -195,7 +196,8 @@ def gemm_plan(M, N, K, batch=1, splitk=1):
 
 
 def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, aux_kind=AUX_NONE, out_f32=None,
-         out_bf16=None, out_pre=None, splitk=1, M=None, N=None, ws=None, K=None, a_kblock=0, kskip_len=None, kskip_steps=0):
+         out_bf16=None, out_pre=None, splitk=1, M=None, N=None, ws=None, K=None, a_kblock=0, kskip_len=None, kskip_steps=0,
+         kskip_tilemask=None):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  A/B: bf16 2-D views (or 3-D for strided batch)."""
     _req(A, torch.bfloat16, "A")
     _req(B, torch.bfloat16, "B")
@@ -243,7 +245,7 @@ def gemm(A, B, *, bias=None, rowscale=None, alpha=1.0, act=ACT_NONE, aux=None, a
     code = load().fbl_gemm_bf16_nt(_p(A), lda, _p(B), ldb, M, N, K, _p(bias), _p(rowscale), float(alpha), act, aux_kind,
                                    _p(aux), ld_aux, _p(out_f32), _p(out_bf16), _p(out_pre), ldc or 0, batch, sA, sB, sC,
                                    sX, sBias, splitk, _p(ws), (ws.numel() if ws is not None else 0), int(a_kblock),
-                                   _p(kskip_len), int(kskip_steps), _stream(), _aux_stream())
+                                   _p(kskip_len), int(kskip_steps), _p(kskip_tilemask), _stream(), _aux_stream())
     _chk(code, "fbl_gemm_bf16_nt")
 
 
@@ -558,13 +560,21 @@ def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS
          "fbl_disent_attn_bwd_ds")
 
 
+def gt_tilemask(relidx, klen, B, S, Sp, span2, neg, rmin, rcnt):
+    """uint32 [B * Sp/64] (as int32 tensor): the 128-row tiles of G^T each 64-row k-step can touch (include/fbl.h)"""
+    mask = torch.empty(B * (Sp // 64), dtype=torch.int32, device=relidx.device)
+    _chk(load().fbl_gt_tilemask(_p(relidx), _p(klen), B, S, Sp, span2, int(neg), int(rmin), int(rcnt), _p(mask), _stream()),
+         "fbl_gt_tilemask")
+    return mask
+
+
 def disent_attn_bwd_shear(neg, X, YT, PT, relidx, out, GT, B, S, Sp, nh, span2, y_head_major=True, klen=None,
-                          rmin=0, rcnt=None, lin=0, border=None, row0=None):
+                          rmin=0, rcnt=None, lin=0, border=None, row0=None, tilemask=None):
     ldout = _rows2d(out, "out")
     sh, sb, sd = head_strides(B, Sp, nh, y_head_major)
     _chk(load().fbl_disent_attn_bwd_shear(int(neg), _p(X), _p(YT), sh, sb, sd, _p(PT), _p(relidx), _p(klen), _p(border), _p(out), ldout,
                                           _p(GT), rmin, span2 if rcnt is None else rcnt, int(lin), B, S, Sp, nh, span2,
-                                          _row0(row0, B, klen), _stream()),
+                                          _row0(row0, B, klen), _p(tilemask), _stream()),
          "fbl_disent_attn_bwd_shear")
 
 

@@ -48,7 +48,7 @@ enum {
   FBL_AUX_ADAPTER_TAIL = 6    /* internal to fbl_adapter_up_resid_fwd; fbl_gemm_bf16_nt rejects it                */
 };
 
-/* Bumped whenever the exported interface changes (6: this header -- fbl_dropout_sum_f32 added); the ctypes binding refuses any other value. */
+/* Bumped whenever the exported interface changes (6: this header -- fbl_dropout_sum_f32, fbl_zero, fbl_heads_to_rows_bf16, fbl_gt_tilemask added; tile masks on the shear pass and the k-skipping GEMM); the ctypes binding refuses any other value. */
 int fbl_abi_version(void);
 
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): bf16 MFMA, fp32 accumulate.  K % 64 == 0, lda/ldb % 8 == 0.
@@ -59,6 +59,9 @@ int fbl_abi_version(void);
  * kskip_len != NULL (split-K / accumulate mode only): K consists of samples of kskip_steps 64-wide k-steps each and step j of
  * sample b is known to be all zero in A when 64*j >= kskip_len[b] (int32, device): such steps are neither read nor
  * multiplied -- the rows of G^T beyond a sample's last valid position (fbl_disent_attn_bwd_shear leaves them unwritten).
+ * kskip_tilemask != NULL (with kskip_len; uint32 per 64-wide k-step, device): bit t set <=> rows [128t, 128t+128) of A can be
+ * non-zero in that k-step; (tile, step) pairs whose bit is clear are neither read nor multiplied (fbl_gt_tilemask: the rows of
+ * G^T outside the window a 64-row step can reach, which fbl_disent_attn_bwd_shear then does not even zero-fill).
  * a_kblock_stride > 0: A is k-blocked, A[m][k] lives at m*lda + (k/32)*a_kblock_stride + k%32 (the G^T layout written
  * by fbl_disent_attn_bwd_shear, lda = 32); 0 = plain K-contiguous rows.
  * aux_stream (may be NULL): a second stream of the caller on the same device.  A multi-round problem runs its last,
@@ -71,7 +74,7 @@ int fbl_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int
                      float* out_f32, void* out_bf16, void* out_pre_bf16, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, int64_t strideAux, int64_t strideBias, int splitk,
                      float* splitk_ws, int64_t splitk_ws_floats, int64_t a_kblock_stride, const int32_t* kskip_len,
-                     int kskip_steps, void* stream, void* aux_stream);
+                     int kskip_steps, const uint32_t* kskip_tilemask, void* stream, void* aux_stream);
 
 /* Host-side query, no launch: the kernel fbl_gemm_bf16_nt uses for a plain (K-contiguous, no k-skip) problem of this
  * shape: 8 = the 8-phase 256x256 / 224x256 kernel (gemm8_kernel; remainder rows of a multi-round problem run as 64x128
@@ -279,6 +282,13 @@ int fbl_disent_attn_probs(const void* q, const void* k, int64_t ldq, const void*
  * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
  * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
+/* mask[b*(Sp/64) + j] (uint32): which 128-row tiles of the gt_rcnt rows of G^T (row 0 = table row gt_rmin) the 64-row k-step j of
+ * sample b can touch (neg as in fbl_disent_attn_bwd_shear; klen optional).  A function of the lengths and the relative-index map only:
+ * computed once per backward pass and handed to every shear launch (gt_tilemask: rows outside the marked tiles are not written)
+ * and to the position-table products (fbl_gemm_bf16_nt kskip_tilemask: not read).  ref: the index arithmetic of
+ * model/deberta.py:870-918 (c2p / p2c gather ranges). */
+int fbl_gt_tilemask(const int16_t* relidx, const int32_t* klen, int B, int S, int Sp, int span2, int neg, int gt_rmin, int gt_rcnt,
+                    uint32_t* mask, void* stream);
 /* The preparation of one attention backward as ONE launch: QT / KT = fbl_head_transpose of q / k (head-major
  * [nh,64,B,Sp]), PQT / PKT = the same of the position projections ([nh,64,span2]), Dv = fbl_attn_rowdot(dO, O).
  * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D). */
@@ -294,7 +304,7 @@ int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_
                               const void* PT, const int16_t* relidx, const int32_t* klen, const int32_t* border,
                               void* out, int64_t ldout,
                               void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
-                              int span2, const int32_t* row0, void* stream);
+                              int span2, const int32_t* row0, const uint32_t* gt_tilemask, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count (a fixed-order fold: reproducible bit for bit); row_lse [N] fp32 out.
