@@ -119,7 +119,7 @@ def pos_table_grads(eng, st, ws):
     Kc = B * Sp
     # split count: 5 at the bench shape (K = B*Sp = 10240).  Measured step time for 2 / 3 / 4 / 5 / 10 slices: 49.20 /
     # 48.90 / 48.89 / 48.56-48.71 / 48.88-48.95 ms (same box) -- half the partial-sum traffic of 10, still short workgroups
-    sk = max(2, min(16, Kc // 2048))
+    sk = max(2, min(16, Kc // 2048), -(-(Kc // 64) // 2048))  # (the k-skipping path lists at most 2048 steps per slice)
     o_pk = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), H + rmin * 2 * H)
     o_pq = torch.as_strided(dpos, (nh, rcnt, 64), (64, 2 * H, 1), rmin * 2 * H)
     kblk = rcnt * 32  # elements between consecutive 32-wide k blocks of G^T
@@ -174,7 +174,7 @@ def pos_table_grads_batched(eng, run, pc):
         T = pc[key_t][:E].view(E * nh, 64, Kc)
         d = L.zeros(E * nh, rcnt, 64, dtype=F32, device=dev)
         # two K slices (the skipping path is the accumulating one), folded deterministically through the workspace
-        L.gemm(a, T, out_f32=d, splitk=2, ws=eng.sk_ws, K=Kc, a_kblock=kblk, kskip_tilemask=tmask, **ks)
+        L.gemm(a, T, out_f32=d, splitk=max(2, -(-(Kc // 64) // 2048)), ws=eng.sk_ws, K=Kc, a_kblock=kblk, kskip_tilemask=tmask, **ks)
         # [e, h, r, 64] fp32 -> [e, r, h*64 + .] bf16, into this table's column block
         L.heads_to_rows_bf16(d.view(E, nh, rcnt, 64), dpb[:, :, col0:col0 + H])
     tmp = torch.empty(E, rcnt, H, dtype=F32, device=dev)
