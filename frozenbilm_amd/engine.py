@@ -99,6 +99,7 @@ class Engine:
         self.reducer = None  # set by parallel.GradReducer for data-parallel training
         self._pad_bufs = {}
         self._dyz_pool: Dict[tuple, list] = {}  # [N, K_fold] operands of the folded adapter backward with their padding zeroed once
+        self._dyz_shape = None                   # ... of the current batch shape only
         self.params_version = 0  # bumped by FusedAdam.step (which updates the flat buffer through raw pointers)
         self._ops_version = None
         self.skip_dead_layer = True
@@ -1058,8 +1059,8 @@ class Engine:
                                   for nm, seg in recs], A=A)
             kept = {id(r) for r in rest}
             for rec in pend:  # [dy | dz | 0] operands whose last reader has now been enqueued go back to the pool (same stream)
-                if id(rec) not in kept and rec[4] is not None:
-                    self._dyz_pool.setdefault(tuple(rec[4].shape), []).append(rec[4])
+                if id(rec) not in kept and rec[4] is not None and tuple(rec[4].shape) == self._dyz_shape:
+                    self._dyz_pool.setdefault(self._dyz_shape, []).append(rec[4])  # (buffers of an earlier batch shape are dropped)
             pend[:] = rest
         if red is not None:  # a finished stage is final once none of ITS adapters has a parked product left (any order: the
             # repeated last layer waits one launch longer than the layers behind it, and must not hold their buckets back)
@@ -1103,6 +1104,9 @@ class Engine:
             # blocks have been enqueued (_dw_flush).  Captured steps and the immediate-launch route allocate as before.
             pooled = None
             can_pool = (not torch.cuda.is_current_stream_capturing() and ad["a1"]["Ap"] <= 256 and H % 8 == 0 and not self.dw_on_side)
+            if can_pool and self._dyz_shape != (N, self.Kf1):  # a new batch shape (text padded to the longest sample): one pool, of
+                self._dyz_pool.clear()                           # the current shape only -- never one per shape seen
+                self._dyz_shape = (N, self.Kf1)
             free = self._dyz_pool.get((N, self.Kf1)) if can_pool else None
             if free:
                 dyz = pooled = free.pop()

@@ -147,7 +147,7 @@ def test_adapter_gradient_grouping_policy(monkeypatch):
     nL = 8
     names = lambda li: [f"layer.{li}.a1", f"layer.{li}.a2"]
     G = {n + sfx: n for li in range(nL) for n in names(li) for sfx in (".up.weight", ".down.weight", ".down.bias")}
-    eng = types.SimpleNamespace(dw_group=6, G=G, _bucket_key=lambda n: "layer" + n.split(".")[1], _dyz_pool={})
+    eng = types.SimpleNamespace(dw_group=6, G=G, _bucket_key=lambda n: "layer" + n.split(".")[1], _dyz_pool={}, _dyz_shape=None)
     run = types.SimpleNamespace(dw_pending=[], dw_ready_keys=[], dw_count=0)
     ready = []
     red = types.SimpleNamespace(ready=ready.append)
