@@ -25,6 +25,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                   fwd+bwd, threads = physical cores), rank 0, N=1 only.
   eval_forward -- the eval-mode forward alone (north_star's ">= 40 % of peak on the fused forward"), timed in the same run.
   host         -- host cost of enqueueing one step, measured where the GPU cannot hide it (same launch sequence at B=1).
+
+At --gpus 1 without a launcher the measurement runs in a child process (supervise_single_rank): if that process dies before
+it printed its line (a signal, not a Python exception) it is started once more and the line says `"attempts": 2`; `--no-retry`
+measures in this process (what the tools that put rocprofv3 in front of this script do).
 """
 from __future__ import annotations
 
@@ -99,6 +103,9 @@ def main():
                     help="do not re-measure roofline.traffic (two short rocprofv3 --pmc child runs of this script); the newest "
                          "committed profiles/*_traffic.json is reported instead")
     ap.add_argument("--prewarm", type=int, default=PREWARM_STEPS, help=argparse.SUPPRESS)
+    ap.add_argument("--no-retry", action="store_true",
+                    help="measure in this process (default at --gpus 1: in a child process that is started once more if it dies "
+                         "without printing its line)")
     ap.add_argument("--packed-rows", action="store_true",
                     help="time the step with model.packed_rows = True (NOT the headline: reported under its own metric name; "
                          "for profiling the packed step)")
@@ -117,6 +124,11 @@ def main():
                     help="mlm = BASELINE configs[1] (the headline); videoqa = configs[3] (zero-shot open-ended eval loop, "
                          "n_ans=1000); mc = configs[4] (4-way multiple choice, B=8, S=512)")
     args = ap.parse_args()
+    if _wants_supervisor(args):
+        sys.exit(supervise_single_rank())
+    import faulthandler
+
+    faulthandler.enable()  # a SIGSEGV / SIGABRT of the measuring process leaves a Python traceback on stderr instead of nothing
     if args.workload != "mlm":
         return run_downstream(args)
     if args.training_graphs:  # (a replayed step issues no launches the roofline instrumentation could bracket)
@@ -424,6 +436,9 @@ def main():
             "box_calibration": box,
         }
         out.update(extras)
+        if os.environ.get(CHILD_MARK) == "2":  # second attempt of supervise_single_rank: say so, and how the first one ended
+            out["attempts"] = 2
+            out["first_attempt_exit_status"] = int(os.environ.get("FBL_BENCH_FIRST_RC", "0"))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -598,6 +613,44 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=Fals
             "args.delayed_loss_check": bool(delayed), "model.training_graphs": bool(graphs), "args.packed_rows": bool(packed)}
 
 
+CHILD_MARK = "FBL_BENCH_MEASURING"  # set in the environment of the process that measures (never read by the library)
+
+
+def _wants_supervisor(args) -> bool:
+    """The plain single-GPU invocation (the driver's `python bench.py --gpus 1 ...`) measures in a child process.  Not when this
+    process already is that child, a rank of a launcher, or runs under rocprofv3 (the profile must be the measuring process's own)."""
+    if args.gpus != 1 or "WORLD_SIZE" in os.environ or os.environ.get(CHILD_MARK) or args.no_retry:
+        return False
+    return not any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
+
+
+def supervise_single_rank(cmd=None) -> int:
+    """Run the measurement in a child process and pass its output through.  If the child dies WITHOUT having printed its JSON line
+    (killed by a signal, out-of-memory killer of a shared box, a crash in a driver library: seen once in this round's ~40 runs,
+    silently, 25 s after start), run it once more; the line of the second attempt carries `"attempts": 2` and how the first one ended.
+    A child that fails with an ordinary Python exception (exit status 1) is NOT retried -- that is a bug, not a box."""
+    import subprocess
+
+    cmd = cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    first_rc = None
+    for attempt in (1, 2):
+        env = dict(os.environ, **{CHILD_MARK: str(attempt)})
+        if first_rc is not None:
+            env["FBL_BENCH_FIRST_RC"] = str(first_rc)
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+        got_line = False
+        for line in p.stdout:
+            got_line |= line.startswith("{") and '"metric"' in line
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = p.wait()
+        if got_line or rc in (0, 1, 2) or attempt == 2:
+            return rc if rc >= 0 else 128 - rc
+        first_rc = rc
+        print(f"[bench] the measuring process ended with status {rc} before printing its line; running it once more", file=sys.stderr)
+    return 1
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
     environment torch.distributed.run would set, rendezvous on 127.0.0.1) and pass rank 0's JSON line through."""
@@ -744,7 +797,7 @@ def measure_traffic_live(args):
     whole = 0.0
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", **{CHILD_MARK: "pmc"})
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 out = os.path.join(td, c)
                 cmd = [exe, "--pmc", c, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable, here, "--steps", "1", "--warmup",

@@ -211,3 +211,44 @@ def test_packed_row_layout_of_a_ragged_batch():
     assert (pk2.row0[1:] - pk2.row0[:-1]).tolist() == [T + 4, S, T + 8, T] and int(pk2.inv[rows[0]]) >= 0
     # nothing to drop -> no packing
     assert Engine._make_packing(eng, torch.ones(B, S, dtype=torch.int32), None, rows, B, S, T) is None
+
+
+def test_bench_supervisor_restarts_a_measuring_process_that_died_silently(capfd):
+    """bench.py at --gpus 1 measures in a child process: one that is killed before it printed its JSON line is started once
+    more (and only once); an ordinary Python failure (exit status 1) is passed through without a second attempt."""
+    import sys
+
+    import bench
+
+    dies_first = ("import os, signal, json\n"
+                  f"a = os.environ['{bench.CHILD_MARK}']\n"
+                  "print('starting', a, flush=True)\n"
+                  "if a == '1': os.kill(os.getpid(), signal.SIGKILL)\n"
+                  "print(json.dumps({'metric': 'm', 'first': os.environ.get('FBL_BENCH_FIRST_RC')}), flush=True)\n")
+    assert bench.supervise_single_rank([sys.executable, "-c", dies_first]) == 0
+    out, err = capfd.readouterr()
+    assert out.count("starting") == 2 and out.count('"metric"') == 1 and '"first": "-9"' in out
+    assert "once more" in err
+    always_dies = "import os, signal\nprint('x', flush=True)\nos.kill(os.getpid(), signal.SIGSEGV)\n"
+    assert bench.supervise_single_rank([sys.executable, "-c", always_dies]) == 128 + 11
+    out, _ = capfd.readouterr()
+    assert out.count("x") == 2
+    raises = "print('y', flush=True)\nraise SystemExit(1)\n"
+    assert bench.supervise_single_rank([sys.executable, "-c", raises]) == 1
+    out, _ = capfd.readouterr()
+    assert out.count("y") == 1
+    # who supervises: the plain single-GPU call only
+    ns = types.SimpleNamespace(gpus=1, no_retry=False)
+    import os
+
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k in ("WORLD_SIZE", bench.CHILD_MARK) or k.startswith(("ROCP_", "ROCPROF"))}
+    try:
+        assert bench._wants_supervisor(ns)
+        assert not bench._wants_supervisor(types.SimpleNamespace(gpus=2, no_retry=False))
+        assert not bench._wants_supervisor(types.SimpleNamespace(gpus=1, no_retry=True))
+        for k in ("WORLD_SIZE", bench.CHILD_MARK, "ROCP_TOOL_LIBRARIES"):
+            os.environ[k] = "1"
+            assert not bench._wants_supervisor(ns)
+            del os.environ[k]
+    finally:
+        os.environ.update(saved)

@@ -9,6 +9,6 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY 
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_VALU"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/$1/s$i -o p -- python $R/bench.py --steps 1 --warmup 0 --prewarm 2 \
-    --no-cpu-baseline --no-roofline --no-extras --no-traffic > $R/gpurun_out/$1/s$i.log 2>&1
+    --no-cpu-baseline --no-roofline --no-extras --no-traffic --no-retry > $R/gpurun_out/$1/s$i.log 2>&1
 done
 cd $R; python tools/pmc_step_summary.py gpurun_out/$1 3

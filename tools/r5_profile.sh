@@ -5,7 +5,7 @@ T=${1:-r5/final}
 mkdir -p gpurun_out/$T/prof gpurun_out/$T/traffic gpurun_out/$T/pmc
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/$T/bench_final.json 2> /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$T/prof -o r5 -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/$T/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$T/prof -o r5 -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --no-retry > $R/gpurun_out/$T/prof.log 2>&1
 cd $R
 python tools/prof_streams.py gpurun_out/$T/prof/r5_results.db 17 1 > gpurun_out/$T/q1.txt 2>&1
 python tools/prof_summary.py gpurun_out/$T/prof/r5_results.db 17 45 > gpurun_out/$T/all.txt 2>&1
