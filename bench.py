@@ -129,6 +129,9 @@ def main():
     import faulthandler
 
     faulthandler.enable()  # a SIGSEGV / SIGABRT of the measuring process leaves a Python traceback on stderr instead of nothing
+    import atexit
+
+    atexit.register(_report_exit_without_line)
     if args.workload != "mlm":
         return run_downstream(args)
     if args.training_graphs:  # (a replayed step issues no launches the roofline instrumentation could bracket)
@@ -146,6 +149,7 @@ def main():
     # N > 1 code path (rank spawning, reducer, max-over-ranks timing) can be exercised on a one-GPU box.
     share = bool(args.share_gpu)
     local = 0 if share else local
+    _phase("set_device")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -158,15 +162,19 @@ def main():
     from frozenbilm_amd.optim import FusedAdam
     from frozenbilm_amd.parallel import GradReducer
 
+    _phase("load libfbl.so")
     L.load()
+    _phase("build model (host)")
     cfg = DebertaV2Config(num_hidden_layers=args.layers)
     torch.manual_seed(0)
     t_build = time.time()
     model = DebertaV2ForMaskedLM(cfg, max_feats=10, features_dim=1024, ds_factor_attn=8, ds_factor_ff=8, dropout=0.1)
+    _phase("model.to(device)")
     model.to(dev)
     model.train(not args.eval_forward)
     model.training_graphs = bool(args.training_graphs)
     model.packed_rows = bool(args.packed_rows)
+    _phase("engine (operand copies)")
     eng = model.engine()
     opt = FusedAdam(model, lr=3e-5, betas=(0.9, 0.95))
     # --force-reducer exercises the bucket bookkeeping on a single GPU (the collectives are skipped at world 1)
@@ -200,8 +208,10 @@ def main():
     # clock / power-state ramp: a box that has just been handed over can sit in a low-power state for the first second of
     # load (one round-1 run measured 2x slower end to end for that reason), so a fixed untimed pre-warm precedes the W
     # warm-up steps the contract asks for
+    _phase("pre-warm steps")
     for _ in range(args.prewarm):
         step()
+    _phase("warm-up + timed steps")
     for _ in range(args.warmup):
         loss = step()
     sync()
@@ -235,6 +245,7 @@ def main():
     # step on most of them and 57.6 on one -- so the line carries what THIS box gives a fixed, well-known launch: the 8-phase
     # GEMM at 4096^3 (1270-1370 TFLOP/s on a healthy box), right after the timed region.
     box = None
+    _phase("box calibration")
     if rank == 0:
         ca = (torch.rand(4096, 4096, device=dev) * 2 - 1).to(torch.bfloat16)
         cb = (torch.rand(4096, 4096, device=dev) * 2 - 1).to(torch.bfloat16)
@@ -252,6 +263,7 @@ def main():
         del ca, cb, co
 
     roofline = None
+    _phase("roofline replay / traffic passes")
     if not args.no_roofline:
         # every rank replays the instrumented steps (they contain the gradient collectives); rank 0 reports its own
         roofline = measure_gemm_roofline(L, step)
@@ -264,6 +276,7 @@ def main():
         sync()
 
     extras = {}
+    _phase("extras")
     full_cfg = args.layers == 24 and B == 32 and Lt == 256
     if not args.no_extras and not args.eval_forward:
         def timed(fn, n):
@@ -391,6 +404,7 @@ def main():
                                                                                               True, packed=True)}
 
     cpu_baseline = cpu_baseline_cfg1 = None
+    _phase("cpu baselines")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = measure_cpu_baseline(model, cfg, T, F, Lt, fwd_only=args.eval_forward)
         cpu_baseline_cfg1 = measure_cpu_baseline_cfg1()
@@ -439,7 +453,9 @@ def main():
         if os.environ.get(CHILD_MARK) == "2":  # second attempt of supervise_single_rank: say so, and how the first one ended
             out["attempts"] = 2
             out["first_attempt_exit_status"] = int(os.environ.get("FBL_BENCH_FIRST_RC", "0"))
-        print(json.dumps(out))
+            out["first_attempt_last_phase"] = os.environ.get("FBL_BENCH_FIRST_PHASE", "unknown")
+        print(json.dumps(out), flush=True)
+    _phase("done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -547,7 +563,8 @@ def run_downstream(args):
                                  n_ans=1000 if args.workload == "videoqa" else 2)
     model.to(dev).eval()
     print(json.dumps(measure_downstream(model, cfg, args.workload, args.steps, args.warmup, args.layers,
-                                        graphs=not args.no_inference_graphs)))
+                                        graphs=not args.no_inference_graphs)), flush=True)
+    _phase("done")
 
 
 def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=False, packed=False):
@@ -614,6 +631,29 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=Fals
 
 
 CHILD_MARK = "FBL_BENCH_MEASURING"  # set in the environment of the process that measures (never read by the library)
+PHASE_FILE = "FBL_BENCH_PHASE_FILE"  # where the measuring process leaves the name of the phase it is in (for the supervisor)
+_T_START = time.time()
+_PHASE = ["start"]
+
+
+def _phase(name: str):
+    """breadcrumb: which part of the run the measuring process is in (read by the supervisor if the process dies without a line)"""
+    _PHASE[0] = name
+    path = os.environ.get(PHASE_FILE)
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(f"{name} (+{time.time() - _T_START:.1f} s)")
+        except OSError:
+            pass
+
+
+def _report_exit_without_line():
+    """atexit of the measuring process: an exit that came through the interpreter (sys.exit, an exception) says where it was;
+    an exit from inside a native library (exit(), _exit()) never gets here -- the supervisor then only has the phase file"""
+    if _PHASE[0] != "done":
+        print(f"[bench] the interpreter is exiting before the line was printed; phase: {_PHASE[0]} (+{time.time() - _T_START:.1f} s)",
+              file=sys.stderr, flush=True)
 
 
 def _wants_supervisor(args) -> bool:
@@ -626,28 +666,44 @@ def _wants_supervisor(args) -> bool:
 
 def supervise_single_rank(cmd=None) -> int:
     """Run the measurement in a child process and pass its output through.  If the child dies WITHOUT having printed its JSON line
-    (killed by a signal, out-of-memory killer of a shared box, a crash in a driver library: seen once in this round's ~40 runs,
-    silently, 25 s after start), run it once more; the line of the second attempt carries `"attempts": 2` and how the first one ended.
-    A child that fails with an ordinary Python exception (exit status 1) is NOT retried -- that is a bug, not a box."""
+    (seen twice in this round's ~45 runs, both silently and within half a minute of the start), run it once more; the line of the second attempt carries `"attempts": 2` and how the first one ended.
+    The first occurrence left no trace at all; the second (exit status 1, nothing on stdout or stderr, < 30 s after start) is why
+    ANY unsuccessful exit without a line is retried, and why the measuring process leaves breadcrumbs (`_phase`)."""
     import subprocess
+
+    import tempfile
 
     cmd = cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     first_rc = None
-    for attempt in (1, 2):
-        env = dict(os.environ, **{CHILD_MARK: str(attempt)})
-        if first_rc is not None:
-            env["FBL_BENCH_FIRST_RC"] = str(first_rc)
-        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-        got_line = False
-        for line in p.stdout:
-            got_line |= line.startswith("{") and '"metric"' in line
-            sys.stdout.write(line)
-            sys.stdout.flush()
-        rc = p.wait()
-        if got_line or rc in (0, 1, 2) or attempt == 2:
-            return rc if rc >= 0 else 128 - rc
-        first_rc = rc
-        print(f"[bench] the measuring process ended with status {rc} before printing its line; running it once more", file=sys.stderr)
+    fd, phase_path = tempfile.mkstemp(prefix="fbl_bench_phase_", dir="/tmp")
+    os.close(fd)
+    try:
+        for attempt in (1, 2):
+            env = dict(os.environ, **{CHILD_MARK: str(attempt), PHASE_FILE: phase_path})
+            if first_rc is not None:
+                env["FBL_BENCH_FIRST_RC"] = str(first_rc)
+                env["FBL_BENCH_FIRST_PHASE"] = first_phase
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+            got_line = False
+            for line in p.stdout:
+                got_line |= line.startswith("{") and '"metric"' in line
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            rc = p.wait()
+            if got_line or rc == 0 or attempt == 2:
+                return rc if rc >= 0 else 128 - rc
+            first_rc = rc
+            try:
+                first_phase = open(phase_path).read().strip() or "unknown"
+            except OSError:
+                first_phase = "unknown"
+            print(f"[bench] the measuring process ended with status {rc} before printing its line (last phase: {first_phase}); "
+                  "running it once more", file=sys.stderr, flush=True)
+    finally:
+        try:
+            os.unlink(phase_path)
+        except OSError:
+            pass
     return 1
 
 

@@ -579,6 +579,76 @@ def test_train_mode_parity_other_mask_streams(seed):
     assert worst[0] < 2e-2, worst
 
 
+def test_training_trajectory_follows_the_oracle_over_optimizer_steps():
+    """Six steps of the reference's update rule (main.py:67-84: forward in train mode, backward, clip_grad_norm_(0.1), Adam with
+    lr / betas of args.py) on six different batches, the HIP path (FusedAdam: clip folded into the flat update) beside the oracle
+    (torch.optim.Adam + clip_grad_norm_ on ITS OWN parameter trajectory).  Every step the oracle sees the dropout masks and ReLU
+    gates of the HIP step; nothing else is shared, so an error in one step's gradients, in the clip factor or in the moments
+    compounds into the next step's loss.  Checked: loss of every step, worst gradient of every step, and the direction of the
+    accumulated parameter update of every trainable tensor."""
+    from frozenbilm_amd.optim import FusedAdam
+    from tests.dropout_replay import ReplayedMasks
+
+    cfg = _tiny_cfg()
+    B, Lt, steps, lr, clip = 4, 40, 6, 3e-4, 0.1
+    P0 = O.synth_params(cfg, seed=43, std=0.05, ln_jitter=0.1)
+    torch.manual_seed(4242)
+    m = build(cfg, P0, train=True)
+    opt = FusedAdam(m, lr=lr, betas=(0.9, 0.95))
+    Pr = {k: v.clone() for k, v in P0.items()}
+    for k, v in Pr.items():
+        v.requires_grad_(O.is_trainable(k))
+    train_names = [k for k in Pr if O.is_trainable(k)]
+    opt_ref = torch.optim.Adam([Pr[k] for k in train_names], lr=lr, betas=(0.9, 0.95))
+    c = m.config
+    log = []
+    for s in range(steps):
+        batch = synth_batch(cfg, B=B, L=Lt, seed=50 + s)
+        opt.zero_grad()
+        out = m(**to_dev(batch))
+        run = out.__dict__["_run"]
+        masks = ReplayedMasks(run, cfg, cfg.num_attention_heads, c.hidden_dropout_prob, c.attention_probs_dropout_prob, m.adapter_dropout)
+        gates = _gates_of(run, cfg)
+        out.loss.backward()
+        grads = {n: p.grad.float().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}
+        opt.step(clip_max_norm=clip)
+        gn = opt.grad_norm().item()
+        opt_ref.zero_grad()
+        with O.bf16_operands(), O.adapter_gates([g_.view(B, -1, g_.shape[-1]) for g_ in gates]), O.dropout_masks(masks):
+            ref = O.forward(Pr, cfg, **batch)
+            ref["loss"].backward()
+        assert masks.exhausted()
+        worst = max((_rel_fro(grads[n], Pr[n].grad), n) for n in train_names)
+        gn_ref = torch.nn.utils.clip_grad_norm_([Pr[k] for k in train_names], clip).item()
+        opt_ref.step()
+        log.append((out.loss.item(), ref["loss"].item(), worst, gn, gn_ref))
+        del out, run
+    for s, (lh, lo, worst, gn, gn_ref) in enumerate(log):
+        print(f"step {s}: loss {lh:.5f} vs {lo:.5f}, worst grad {worst[0]:.4f} ({worst[1]}), grad norm {gn:.4f} vs {gn_ref:.4f}")
+    assert abs(log[0][0] - log[-1][0]) > 1e-3  # (different batches, moving parameters: not one number six times)
+    for lh, lo, worst, gn, gn_ref in log:
+        assert abs(lh - lo) < 2e-2, log
+        assert worst[0] < 3e-2, log
+        assert abs(gn - gn_ref) < 2e-2 * gn_ref, log
+    # accumulated update of every trainable tensor: same direction, same size.  Adam's first steps move every element by ~lr
+    # whatever the size of its gradient, so the elements whose gradient is smaller than the two paths' arithmetic difference
+    # move in a random direction in both: the bound is on the direction of the whole tensor, not per element.
+    cos, size = [], []
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        dh = (p.detach().float().cpu() - P0[n]).flatten()
+        dr = (Pr[n].detach() - P0[n]).flatten()
+        assert dr.abs().max().item() > 0.5 * lr, n  # the parameter moved
+        cos.append((torch.nn.functional.cosine_similarity(dh, dr, dim=0).item(), n))
+        size.append((dh.norm() / dr.norm()).item())
+    print("update cosine, worst five:", sorted(cos)[:5], "size ratio range:", min(size), max(size))
+    assert min(cos)[0] > 0.9, sorted(cos)[:5]
+    assert 0.9 < min(size) and max(size) < 1.1, (min(size), max(size))
+    frozen = "deberta.encoder.layer.0.intermediate.dense.weight"
+    assert torch.equal(m.get_param(frozen).float().cpu(), P0[frozen])
+
+
 @pytest.mark.parametrize("ds_attn,ds_ff,ft_ln", [(0, 0, True), (8, 8, False), (0, 8, True), (8, 0, False)],
                          ids=["no-adapters", "ft_ln-off", "ffn-adapter-only", "attn-adapter-only+ft_ln-off"])
 def test_freeze_policy_flag_variants_vs_oracle(ds_attn, ds_ff, ft_ln):

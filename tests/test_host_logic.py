@@ -215,7 +215,8 @@ def test_packed_row_layout_of_a_ragged_batch():
 
 def test_bench_supervisor_restarts_a_measuring_process_that_died_silently(capfd):
     """bench.py at --gpus 1 measures in a child process: one that is killed before it printed its JSON line is started once
-    more (and only once); an ordinary Python failure (exit status 1) is passed through without a second attempt."""
+    more (and only once), whatever its exit status was (the failure this guards against came back as a silent status 1), and
+    the second attempt is told how and where the first one ended."""
     import sys
 
     import bench
@@ -223,12 +224,14 @@ def test_bench_supervisor_restarts_a_measuring_process_that_died_silently(capfd)
     dies_first = ("import os, signal, json\n"
                   f"a = os.environ['{bench.CHILD_MARK}']\n"
                   "print('starting', a, flush=True)\n"
+                  f"open(os.environ['{bench.PHASE_FILE}'], 'w').write('phase-' + a)\n"
                   "if a == '1': os.kill(os.getpid(), signal.SIGKILL)\n"
-                  "print(json.dumps({'metric': 'm', 'first': os.environ.get('FBL_BENCH_FIRST_RC')}), flush=True)\n")
+                  "print(json.dumps({'metric': 'm', 'first': os.environ.get('FBL_BENCH_FIRST_RC'),\n"
+                  "                  'where': os.environ.get('FBL_BENCH_FIRST_PHASE')}), flush=True)\n")
     assert bench.supervise_single_rank([sys.executable, "-c", dies_first]) == 0
     out, err = capfd.readouterr()
-    assert out.count("starting") == 2 and out.count('"metric"') == 1 and '"first": "-9"' in out
-    assert "once more" in err
+    assert out.count("starting") == 2 and out.count('"metric"') == 1 and '"first": "-9"' in out and '"where": "phase-1"' in out
+    assert "once more" in err and "phase-1" in err
     always_dies = "import os, signal\nprint('x', flush=True)\nos.kill(os.getpid(), signal.SIGSEGV)\n"
     assert bench.supervise_single_rank([sys.executable, "-c", always_dies]) == 128 + 11
     out, _ = capfd.readouterr()
@@ -236,7 +239,7 @@ def test_bench_supervisor_restarts_a_measuring_process_that_died_silently(capfd)
     raises = "print('y', flush=True)\nraise SystemExit(1)\n"
     assert bench.supervise_single_rank([sys.executable, "-c", raises]) == 1
     out, _ = capfd.readouterr()
-    assert out.count("y") == 1
+    assert out.count("y") == 2
     # who supervises: the plain single-GPU call only
     ns = types.SimpleNamespace(gpus=1, no_retry=False)
     import os
