@@ -231,6 +231,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     loss_value = float(loss.item())
+    params_finite = bool(torch.isfinite(eng.flat).all().item())  # after prewarm + warm-up + the timed steps
     step_ms_gpu = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]  # diagnostic: per-step GPU timeline
     step_ms_host = [round((b - a) * 1e3, 2) for a, b in zip([t0] + host_marks[:-1], host_marks)]
     ms_per_step = dt / args.steps * 1e3
@@ -295,37 +296,83 @@ def main():
             return d / n
 
         n_x = max(3, min(args.steps, 6))
-        if not args.full_logits:
-            d = timed(lambda: step(True), n_x)
-            extras["with_full_logits"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                                          "note": "same step, .logits read every step: the [B,S,128100] fp32 tensor is produced"}
-        model.eval()
+        batch0 = dict(batch)
+        snap = {"flat": eng.flat.clone(), "m": None if opt._m is None else opt._m.clone(),
+                "v": None if opt._v is None else opt._v.clone(), "step": opt._step}
+
+        class Leg:
+            """One auxiliary measurement.  The headline was measured above: a leg that fails (an exception; the product's training
+            loop stopping the run on a non-finite loss) is recorded under `failed_legs` in the line and costs nothing else -- the
+            model goes back to the state the next leg expects.  After every leg the trainable parameters must be finite; if they
+            are not, the leg is named under `nonfinite_parameters_after` and parameters + Adam moments return to their values at
+            the end of the timed region.  (Single process only: a rank that skipped a leg would leave the others in its
+            collectives.)"""
+
+            def __init__(self, name):
+                self.name = name
+
+            def __enter__(self):
+                _phase("extras: " + self.name)
+                return self
+
+            def __exit__(self, et, ev, tb):
+                failed = et is not None and issubclass(et, (Exception, SystemExit))
+                if failed and world > 1:
+                    return False
+                if failed:
+                    extras.setdefault("failed_legs", {})[self.name] = f"{et.__name__}: {ev}"[:600]
+                    print(f"[bench] extras leg {self.name!r} failed: {et.__name__}: {ev}", file=sys.stderr, flush=True)
+                    model.training_graphs = False
+                    model.__dict__.pop("_train_graphs", None)
+                    model.packed_rows = False
+                    model.train()
+                    batch.clear()
+                    batch.update(batch0)
+                torch.cuda.synchronize()
+                e = model.engine()
+                if e.flat.numel() == snap["flat"].numel() and not bool(torch.isfinite(e.flat).all()):
+                    bad = [n for n in e.order if not bool(torch.isfinite(e.flat[e.offsets[n]: e.offsets[n] + e.named[n].numel()]).all())]
+                    extras.setdefault("nonfinite_parameters_after", []).append({"leg": self.name, "tensors": len(bad), "first": bad[:6]})
+                    print(f"[bench] {len(bad)} trainable tensors are non-finite after extras leg {self.name!r} (first: {bad[:6]}): "
+                          "parameters and Adam moments restored", file=sys.stderr, flush=True)
+                    e.flat.copy_(snap["flat"])
+                    e.params_version += 1
+                    if snap["m"] is not None:
+                        opt._m.copy_(snap["m"])
+                        opt._v.copy_(snap["v"])
+                    opt._step = snap["step"]
+                return failed
 
         def fwd_only():
             with torch.no_grad():
                 return model(**batch).loss
 
-        with model.weights_frozen():  # as main.evaluate runs it: nothing writes to the parameters between these forwards
-            d = timed(fwd_only, n_x)
-        model.train()
         rows_lab = float((batch["labels"] != -100).sum().item()) / B
         ex_f, ex_b = executed_flops_per_sample(S=S, rows_labelled=rows_lab, layers=args.layers)
-        extras["eval_forward"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                                  "algorithmic_tflops": fwd_f * B / d / 1e12, "frac_of_peak": fwd_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
-                                  "executed_tflops": ex_f * B / d / 1e12, "executed_frac_of_peak": ex_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
-                                  "note": "eval-mode forward with labels (loss on the labelled rows; logits filled on access). "
-                                          "algorithmic_* divides the reference's op list (SURVEY 8d: full-vocabulary head on every "
-                                          "row, dead layer-23 pass) by the time; executed_* counts only what this forward ran "
-                                          "(vocabulary GEMM on the labelled rows, 25 layer executions)"}
+        if not args.full_logits:
+            with Leg("with_full_logits"):
+                d = timed(lambda: step(True), n_x)
+                extras["with_full_logits"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                              "note": "same step, .logits read every step: the [B,S,128100] fp32 tensor is produced"}
+        with Leg("eval_forward"):
+            model.eval()
+            with model.weights_frozen():  # as main.evaluate runs it: nothing writes to the parameters between these forwards
+                d = timed(fwd_only, n_x)
+            model.train()
+            extras["eval_forward"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                      "algorithmic_tflops": fwd_f * B / d / 1e12, "frac_of_peak": fwd_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
+                                      "executed_tflops": ex_f * B / d / 1e12, "executed_frac_of_peak": ex_f * B / d / 1e12 / PEAK_BF16_TFLOPS,
+                                      "note": "eval-mode forward with labels (loss on the labelled rows; logits filled on access). "
+                                              "algorithmic_* divides the reference's op list (SURVEY 8d: full-vocabulary head on every "
+                                              "row, dead layer-23 pass) by the time; executed_* counts only what this forward ran "
+                                              "(vocabulary GEMM on the labelled rows, 25 layer executions)"}
         extras["executed_tflops_per_step"] = (ex_f + ex_b) * B / 1e12
         # single-GPU characterisations (host cost, launch graphs, packed rows): not repeated on every rank of a multi-GPU run
         if world == 1:
             # host cost of one step where the GPU cannot hide it: the same launch sequence on a B=1 batch
             small = synth_batch(1, T, F, Lt, cfg.vocab_size, seed=77, device=dev)
             keep = dict(batch)
-            batch.clear(); batch.update(small)
-            d = timed(lambda: step(False), n_x)
-            batch.clear(); batch.update(keep)
+
             def host_issue_ms(n=4):
                 # what the HOST spends issuing one full-size step: the queue is empty when the step starts and nobody waits for
                 # the GPU afterwards (the label count at the start of forward finds its tiny kernel done at once)
@@ -338,55 +385,62 @@ def main():
                 sync()
                 return tot / n * 1e3
 
-            extras["host"] = {"enqueue_ms_per_step": d * 1e3, "issue_ms_per_step": host_issue_ms(),
-                              "note": "enqueue_ms_per_step: wall time per step of the same launch sequence at B=1 (GPU work per launch "
-                                      "negligible: ~1450 dependent launches cost that much on the GPU side too); issue_ms_per_step: "
-                                      "host time to issue one full-size step into an empty queue, nobody waiting for the GPU"}
+            with Leg("host"):
+                batch.clear(); batch.update(small)
+                d = timed(lambda: step(False), n_x)
+                batch.clear(); batch.update(keep)
+                extras["host"] = {"enqueue_ms_per_step": d * 1e3, "issue_ms_per_step": host_issue_ms(),
+                                  "note": "enqueue_ms_per_step: wall time per step of the same launch sequence at B=1 (GPU work per launch "
+                                          "negligible: ~1450 dependent launches cost that much on the GPU side too); issue_ms_per_step: "
+                                          "host time to issue one full-size step into an empty queue, nobody waiting for the GPU"}
             # the same step with model.training_graphs (forward and backward replayed as two hipGraphs; clip + Adam eager): GPU
             # time per step, and the host cost where the GPU cannot hide it (B=1, as `host` above)
-            model.training_graphs = True
-            d = timed(lambda: step(False), n_x)
-            batch.clear(); batch.update(small)
-            dh = timed(lambda: step(False), n_x)
-            batch.clear(); batch.update(keep)
-            gi = host_issue_ms()
-            model.training_graphs = False
-            model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
-            extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                                      "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
-                                      "note": "model.training_graphs = True: forward and backward of the step replayed as two hipGraphs "
-                                              "(frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step as under `host`"}
+            with Leg("graphed_step"):
+                model.training_graphs = True
+                d = timed(lambda: step(False), n_x)
+                batch.clear(); batch.update(small)
+                dh = timed(lambda: step(False), n_x)
+                batch.clear(); batch.update(keep)
+                gi = host_issue_ms()
+                model.training_graphs = False
+                model.__dict__.pop("_train_graphs", None)  # (each captured shape holds one step's activations)
+                extras["graphed_step"] = {"value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                                          "enqueue_ms_per_step": dh * 1e3, "issue_ms_per_step": gi,
+                                          "note": "model.training_graphs = True: forward and backward of the step replayed as two "
+                                                  "hipGraphs (frozenbilm_amd/train_graph.py); enqueue_ms_per_step / issue_ms_per_step "
+                                                  "as under `host`"}
             # the same step with model.packed_rows: the batch is ragged (text 32..256 tokens, 1..10 frames) and every GEMM,
             # LayerNorm and adapter of the headline step also processes the padding rows behind each sample's last token, as
             # the reference does.  Packed, those rows do not exist.  A separately named object: its fraction
             # counts EXECUTED FLOPs only (per sample: the op list of executed_flops_per_sample at that sample's own length)
             # and earns nothing against the padded op list; the headline `value` stays reference-shaped.
-            model.packed_rows = True
-            try:
-                d = timed(lambda: step(False), n_x)
-                with torch.no_grad():
-                    model.eval()
-                    pk = model(**batch)._run.pk
-                    with model.weights_frozen():
-                        d_f = timed(fwd_only, n_x)
-                    model.train()
-            finally:
-                model.packed_rows = False
-            if pk is not None:
-                plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
-                ex_p = [executed_flops_per_sample(S=s, rows_labelled=rows_lab, layers=args.layers) for s in plen]
-                exf_p, exb_p = sum(e[0] for e in ex_p), sum(e[1] for e in ex_p)
-                extras["packed_rows"] = {
-                    "value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
-                    "rows": int(pk.n), "grid_rows": B * S,
-                    "executed_tflops_per_step": (exf_p + exb_p) / 1e12,
-                    "executed_frac_of_peak": (exf_p + exb_p) / d / 1e12 / PEAK_BF16_TFLOPS,
-                    "eval_forward": {"value": world * B / d_f, "unit": "samples/s", "ms_per_step": d_f * 1e3,
-                                     "executed_frac_of_peak": exf_p / d_f / 1e12 / PEAK_BF16_TFLOPS},
-                    "note": "model.packed_rows = True (opt-in extension, frozenbilm_amd.engine.Packing): the same batch, same "
-                            "loss and gradients (tests/test_gpu_model.py::test_packed_rows_*), without the padding rows behind "
-                            "each sample's last token; NOT the headline: the reference computes those rows and the headline "
-                            "counts them"}
+            with Leg("packed_rows"):
+                model.packed_rows = True
+                try:
+                    d = timed(lambda: step(False), n_x)
+                    with torch.no_grad():
+                        model.eval()
+                        pk = model(**batch)._run.pk
+                        with model.weights_frozen():
+                            d_f = timed(fwd_only, n_x)
+                        model.train()
+                finally:
+                    model.packed_rows = False
+                if pk is not None:
+                    plen = (pk.row0[1:] - pk.row0[:-1]).tolist()
+                    ex_p = [executed_flops_per_sample(S=s, rows_labelled=rows_lab, layers=args.layers) for s in plen]
+                    exf_p, exb_p = sum(e[0] for e in ex_p), sum(e[1] for e in ex_p)
+                    extras["packed_rows"] = {
+                        "value": world * B / d, "unit": "samples/s", "ms_per_step": d * 1e3, "steps": n_x,
+                        "rows": int(pk.n), "grid_rows": B * S,
+                        "executed_tflops_per_step": (exf_p + exb_p) / 1e12,
+                        "executed_frac_of_peak": (exf_p + exb_p) / d / 1e12 / PEAK_BF16_TFLOPS,
+                        "eval_forward": {"value": world * B / d_f, "unit": "samples/s", "ms_per_step": d_f * 1e3,
+                                         "executed_frac_of_peak": exf_p / d_f / 1e12 / PEAK_BF16_TFLOPS},
+                        "note": "model.packed_rows = True (opt-in extension, frozenbilm_amd.engine.Packing): the same batch, same "
+                                "loss and gradients (tests/test_gpu_model.py::test_packed_rows_*), without the padding rows behind "
+                                "each sample's last token; NOT the headline: the reference computes those rows and the headline "
+                                "counts them"}
         if world == 1 and full_cfg:
             # the loop a user runs (main.train_one_epoch: host-side masking, copies, loss logging) with NO opt-in set
             # (`reference_order`: what the two-line swap of INTEGRATION.md gives -- the backward is enqueued before the host reads
@@ -395,13 +449,12 @@ def main():
             extras["train_one_epoch"] = {"note": "frozenbilm_amd.main.train_one_epoch over synthetic batches that start on the "
                                                  "host (CPU mask_tokens, H2D copies, loss logging): the loop, not the step body; "
                                                  "reference_order = the default loop, no opt-in (loss read after the backward "
-                                                 "is enqueued, before optimizer.step: same stop-before-update behaviour as main.py:73-84)",
-                                         "reference_order": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False),
-                                         "delayed_loss_check": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, True),
-                                         "reference_order_graphed": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, False,
-                                                                                       graphs=True),
-                                         "delayed_loss_check_packed_rows": measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l,
-                                                                                              True, packed=True)}
+                                                 "is enqueued, before optimizer.step: same stop-before-update behaviour as main.py:73-84)"}
+            for key, kw in (("reference_order", dict(delayed=False)), ("delayed_loss_check", dict(delayed=True)),
+                            ("reference_order_graphed", dict(delayed=False, graphs=True)),
+                            ("delayed_loss_check_packed_rows", dict(delayed=True, packed=True))):
+                with Leg("train_one_epoch." + key):
+                    extras["train_one_epoch"][key] = measure_train_loop(model, cfg, opt, B, T, F, Lt, n_l, **kw)
 
     cpu_baseline = cpu_baseline_cfg1 = None
     _phase("cpu baselines")
@@ -413,14 +466,15 @@ def main():
         # BASELINE configs[3] / configs[4] through the product's evaluate loops on the same model (last: the answer table is
         # swapped in and the engine rebuilt), with the loops' opt-in inference graphs and with eager launches
         for wl, key in (("videoqa", "videoqa_eval"), ("mc", "mc_eval")):
-            on = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=True)
-            off = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False)
-            on["eager_launches"] = {"value": off["value"], "ms_per_step": off["ms_per_step"]}
-            pkd = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False, packed=True)
-            on["packed_rows"] = {"value": pkd["value"], "ms_per_step": pkd["ms_per_step"],
-                                 "note": "model.packed_rows = True (eager launches): the same loop without the padding rows "
-                                         "behind each sample's last token"}
-            extras[key] = on
+            with Leg(key):
+                on = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=True)
+                off = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False)
+                on["eager_launches"] = {"value": off["value"], "ms_per_step": off["ms_per_step"]}
+                pkd = measure_downstream(model, cfg, wl, n_x, 1, args.layers, graphs=False, packed=True)
+                on["packed_rows"] = {"value": pkd["value"], "ms_per_step": pkd["ms_per_step"],
+                                     "note": "model.packed_rows = True (eager launches): the same loop without the padding rows "
+                                             "behind each sample's last token"}
+                extras[key] = on
 
     if rank == 0:
         full = args.layers == 24 and B == 32 and Lt == 256
@@ -441,7 +495,8 @@ def main():
                        **({"model.training_graphs": True} if args.training_graphs else {}),
                        **({"model.packed_rows": True} if args.packed_rows else {})},
             "prewarm_steps": PREWARM_STEPS, "step_ms_gpu": step_ms_gpu, "step_ms_host": step_ms_host, "loadavg": os.getloadavg()[0],
-            "loss": loss_value, "host_loop_ms_per_step": t_host / args.steps * 1e3,
+            "loss": loss_value, "trainable_parameters_finite_after_timed_steps": params_finite,
+            "host_loop_ms_per_step": t_host / args.steps * 1e3,
             # data parallel: ranks RCCL's collectives ran over (0 = no reducer / not the nccl backend) and where in backward
             # they are launched (parallel.GradReducer.overlap; --dp-overlap)
             "rccl_ranks": red.rccl_ranks if red is not None else 0, "dp_overlap": red.overlap if red is not None else None,
@@ -614,14 +669,18 @@ def measure_train_loop(model, cfg, opt, B, T, F, Lt, steps, delayed, graphs=Fals
                                   fraction_warmup_steps=0.1, delayed_loss_check=delayed, packed_rows=bool(packed))
     model.train()
     model.training_graphs = bool(graphs)
+    said = io.StringIO()  # the loop's own prints (MetricLogger lines; the message in front of its sys.exit(1) on a non-finite loss)
     try:
-        with contextlib.redirect_stdout(io.StringIO()):
+        with contextlib.redirect_stdout(said):
             P_main.train_one_epoch(model, Tok(), Loader(batches[:n_warm]), opt, model.device, 0, largs, 0.1)  # warm-up
             torch.cuda.synchronize()
             t0 = time.time()
             P_main.train_one_epoch(model, Tok(), Loader(batches[n_warm:]), opt, model.device, 0, largs, 0.1)
             torch.cuda.synchronize()
         dt = time.time() - t0
+    except SystemExit as e:  # main.py:75-78 behaviour of the loop; here: a failed measurement WITH its message, not a silent exit
+        tail = " | ".join(said.getvalue().strip().splitlines()[-3:])
+        raise RuntimeError(f"main.train_one_epoch stopped the run with exit status {e.code}: {tail}") from None
     finally:
         model.training_graphs = False
         model.packed_rows = False
