@@ -1113,11 +1113,34 @@ extern "C" int fbl_dropout_f32(const float* in, float p_drop, uint64_t seed, con
   FBL_CHECK_LAUNCH();
   return 0;
 }
+// p[0, bytes) = 0 as a KERNEL: 16-byte stores over the aligned body, byte stores for a ragged head / tail.  Not hipMemsetAsync:
+// inside a captured step that becomes a memset node of the graph, the only non-kernel nodes the step would have -- and the buffers
+// zeroed this way are all accumulated into by the next kernel (split-K partial sums, the loss accumulator, the position-table
+// gradients), so a fill that is not ordered exactly like a kernel turns into garbage or NaN in every gradient.  Replayed steps
+// produced non-finite gradients about once in 500 replays while the fills were memset nodes (bench.py `graphed_step`, round 5);
+// eager steps never did.
+__global__ void zero_kernel(unsigned char* p, long bytes, long head, long body16) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  uint4* b = (uint4*)(p + head);
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = t; i < body16; i += stride) b[i] = z;
+  const long tail0 = head + body16 * 16;
+  for (long i = t; i < head; i += stride) p[i] = 0;
+  for (long i = tail0 + t; i < bytes; i += stride) p[i] = 0;
+}
 extern "C" int fbl_zero(void* p, int64_t bytes, void* stream) {
   if (bytes <= 0) return 0;
   if (!p) return FBL_ERR_ARG;
-  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
-  return e == hipSuccess ? 0 : (int)e;
+  long head = (long)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > bytes) head = bytes;
+  const long body16 = (bytes - head) / 16;
+  long blocks = (body16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;  // grid-stride: 16 workgroups per CU keep every HBM channel busy
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, (long)bytes, head, body16);
+  FBL_CHECK_LAUNCH();
+  return 0;
 }
 extern "C" int fbl_heads_to_rows_bf16(const float* src, void* dst_bf16, int E, int nh, int rows, int64_t ld_dst, void* stream) {
   if (E <= 0 || nh <= 0 || rows <= 0) return 0;

@@ -346,7 +346,10 @@ int fbl_dropout_bf16(void* inout_bf16, float p_drop, uint64_t seed, const uint64
  * executions, each through the mask its forward drew, folded in one pass.  ref: autograd of model/deberta.py:779 (pos_dropout)
  * summed over the 24 + 2 executions that share `rel_embeddings` (:507-575, :1382-1412). */
 #define FBL_DROPSUM_MAX_SLICES 64
-/* p[0 .. bytes) = 0 on `stream` (hipMemsetAsync): the zero fills of the step (gradient accumulators, split-K targets) */
+/* p[0 .. bytes) = 0 on `stream`: the zero fills of the step (gradient accumulators, split-K targets, the loss accumulator).  A
+ * kernel launch like every other entry point (16-byte stores, byte stores for an unaligned head / tail) and NOT hipMemsetAsync:
+ * a captured step then consists of kernel nodes only, ordered like eager launches (the memset-node version produced non-finite
+ * gradients in about one replay of 500). */
 int fbl_zero(void* p, int64_t bytes, void* stream);
 /* dst[e][r][h*64 + c] (bf16, row stride ld_dst elements, ld_dst >= nh*64) = src[e][h][r][c] (fp32, contiguous [E][nh][rows][64]):
  * per-head results of a strided-batch GEMM -> the [rows, heads*64] operand of the next one (position-table gradients,

@@ -143,6 +143,15 @@ def test_heads_to_rows_and_zero(L):
     assert L.zero_(t) is t and (t == 0).all()
     z = L.zeros(7, 3, dtype=BF16, device=DEV)
     assert z.shape == (7, 3) and (z == 0).all()
+    # any byte range: unaligned start, ragged tail, neighbours untouched; a large fill (grid-stride path)
+    raw = torch.full((4099,), 7, dtype=torch.uint8, device=DEV)
+    for off, n in ((0, 4099), (1, 15), (3, 64), (13, 4000), (16, 1), (4098, 1)):
+        raw.fill_(7)
+        L.zero_(raw[off: off + n])
+        assert (raw[off: off + n] == 0).all() and (raw[:off] == 7).all() and (raw[off + n:] == 7).all(), (off, n)
+    big = torch.full((50_000_003,), 1.0, device=DEV)
+    L.zero_(big[1:])
+    assert big[0].item() == 1.0 and not big[1:].any()
 
 
 def test_gemm_asymmetric_identity(L):

@@ -24,6 +24,11 @@ ap.add_argument("--phases", default="padded,logits,eval,b1,graphed,packed,padded
 ap.add_argument("--pmc-first", action="store_true",
                 help="before the phases: the two `rocprofv3 --pmc` child runs bench.py makes for roofline.traffic (another process "
                      "collecting counters on this GPU while this one holds its context), as in a default bench run")
+ap.add_argument("--poison-vram", action="store_true",
+                help="before every phase: release the allocator's cache, fill 90 %% of the free device memory with the bit pattern "
+                     "0x7FC07FC0 (NaN as fp32 and as both bf16 halves), release it again -- segments the allocator (or a graph's "
+                     "private pool) then gets from the driver hold NaN wherever nobody writes: reads of unwritten memory AND reads "
+                     "past the end of a tensor show up (what a process finds in VRAM that an earlier process left there)")
 ap.add_argument("--cycles", type=int, default=1, help="repeat the phase list (soak: --no-poison --cycles 30 --sparse-checks)")
 ap.add_argument("--sparse-checks", action="store_true",
                 help="check at the END of a phase only: its steps run back to back, as in bench.py (a check synchronises)")
@@ -75,6 +80,24 @@ def restore():
         opt._m.zero_()
         opt._v.zero_()
     print("    (parameters and optimizer state restored)", flush=True)
+
+
+def poison_vram(frac=0.9):
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    left, chunks = int(free * frac), []
+    while left > (1 << 28):
+        sz = min(8 << 30, left)
+        t = _empty(sz // 4, dtype=torch.int32, device=dev)
+        t.fill_(0x7FC07FC0)
+        chunks.append(t)
+        left -= sz
+    torch.cuda.synchronize()
+    n = len(chunks)
+    del chunks, t
+    torch.cuda.empty_cache()
+    print(f"    (device memory poisoned: {n} chunks, {free * frac / 2**30:.0f} GiB)", flush=True)
 
 
 def bad_names(flat):
@@ -138,6 +161,8 @@ t0 = time.time()
 for cyc, ph in ((c, p) for c in range(args.cycles) for p in phases):
     if args.cycles > 1 and ph == phases[0]:
         print(f"--- cycle {cyc} (+{time.time() - t0:.0f} s, findings so far: {bad_total})", flush=True)
+    if args.poison_vram:
+        poison_vram()
     if ph in ("padded", "padded2"):
         for i in range(3):
             step(batch, f"{ph} {i}" + (" last" if i == 2 else ""))
@@ -159,6 +184,26 @@ for cyc, ph in ((c, p) for c in range(args.cycles) for p in phases):
         model.training_graphs = True
         for i in range(4):
             step(batch, f"graphed {i}" + (" last" if i == 3 else ""))
+        model.training_graphs = False
+        model.__dict__.pop("_train_graphs", None)
+    elif ph == "graphed_b1":
+        # bench.py's `graphed_step` leg exactly: B=32 graph (capture + replays), B=1 graph (capture + replays), B=32 replays again
+        model.__dict__["_train_graph_captures"] = 0
+        model.training_graphs = True
+        dense = (cyc % 2 == 1) or not args.sparse_checks
+        for part, b, n in (("B32", batch, 8), ("B1", small, 8), ("B32 again", batch, 4)):
+            for i in range(n):
+                last = i == n - 1
+                if dense:
+                    opt.zero_grad(set_to_none=False)
+                    out = model(**b)
+                    out.loss.backward()
+                    okg = check(f"graphed_b1 c{cyc} {part} {i} after backward", out.loss)
+                    opt.step(clip_max_norm=0.1)
+                    if not (check(f"graphed_b1 c{cyc} {part} {i} after update") and okg):
+                        restore()
+                else:
+                    step(b, f"graphed_b1 c{cyc} {part} {i}" + (" last" if last else ""))
         model.training_graphs = False
         model.__dict__.pop("_train_graphs", None)
     elif ph == "packed":
