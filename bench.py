@@ -140,7 +140,9 @@ def main():
         args.no_extras = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
+        rc = spawn_ranks(args.gpus)
+        _phase("done")  # (this process only launched the ranks: rank 0 printed the line)
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
