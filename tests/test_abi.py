@@ -58,6 +58,12 @@ def test_product_library_reads_no_environment(libpath):
     syms = subprocess.run(["nm", "-D", "--undefined-only", libpath], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in syms
     assert "hipStreamCreate" not in syms
+    # ... and every entry point is kernel launches (+ event fork / join onto the caller's aux stream) only: no memset / memcpy /
+    # allocation calls.  A captured training step then consists of kernel nodes, ordered like eager launches -- the zero fills of the
+    # accumulation targets were hipMemsetAsync for a while (memset nodes in the graphs) and replayed steps produced non-finite
+    # gradients about once in 500 replays.
+    for forbidden in ("hipMemset", "hipMemcpy", "hipMalloc", "hipFree", "hipHostMalloc", "hipDeviceSynchronize", "hipStreamSynchronize"):
+        assert forbidden not in syms, forbidden
 
 
 def test_missing_library_fails_loudly(tmp_path):
