@@ -725,6 +725,20 @@ def _wants_supervisor(args) -> bool:
     return not any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
 
 
+def _die_with_parent_fn():
+    """A function for Popen's preexec_fn (runs in the child between fork and exec): prctl(PR_SET_PDEATHSIG, SIGKILL) -- no measuring
+    process outlives its supervisor on the GPU.  libc is resolved HERE, in the parent: the child only makes the call."""
+    import ctypes
+    import signal
+
+    try:
+        prctl = ctypes.CDLL("libc.so.6", use_errno=True).prctl
+    except Exception:  # noqa: BLE001  (not Linux / no libc by that name: the signal forwarding still covers SIGTERM / SIGINT)
+        return None
+    kill = int(signal.SIGKILL)
+    return lambda: prctl(1, kill, 0, 0, 0) and None
+
+
 def supervise_single_rank(cmd=None) -> int:
     """Run the measurement in a child process and pass its output through.  If the child dies WITHOUT having printed its JSON line
     (seen twice in this round's ~45 runs, both silently and within half a minute of the start), run it once more; the line of the second attempt carries `"attempts": 2` and how the first one ended.
@@ -732,10 +746,14 @@ def supervise_single_rank(cmd=None) -> int:
     ANY unsuccessful exit without a line is retried, and why the measuring process leaves breadcrumbs (`_phase`)."""
     import subprocess
 
+    import signal
     import tempfile
+    import threading
 
     cmd = cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     first_rc = None
+    stopped = []
+    die_with_me = _die_with_parent_fn()
     fd, phase_path = tempfile.mkstemp(prefix="fbl_bench_phase_", dir="/tmp")
     os.close(fd)
     try:
@@ -744,14 +762,26 @@ def supervise_single_rank(cmd=None) -> int:
             if first_rc is not None:
                 env["FBL_BENCH_FIRST_RC"] = str(first_rc)
                 env["FBL_BENCH_FIRST_PHASE"] = first_phase
-            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-            got_line = False
-            for line in p.stdout:
-                got_line |= line.startswith("{") and '"metric"' in line
-                sys.stdout.write(line)
-                sys.stdout.flush()
-            rc = p.wait()
-            if got_line or rc == 0 or attempt == 2:
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, preexec_fn=die_with_me)
+            # whoever stops this process stops the measurement: SIGTERM / SIGINT are passed on, and the child asked the kernel for a
+            # SIGKILL of its own should this process disappear without a chance to do so (a time-out's SIGKILL)
+            def pass_on(s_, f_, p=p):
+                stopped.append(s_)
+                p.send_signal(s_)
+
+            old = {sg: signal.signal(sg, pass_on) for sg in (signal.SIGTERM, signal.SIGINT)} \
+                if threading.current_thread() is threading.main_thread() else {}
+            try:
+                got_line = False
+                for line in p.stdout:
+                    got_line |= line.startswith("{") and '"metric"' in line
+                    sys.stdout.write(line)
+                    sys.stdout.flush()
+                rc = p.wait()
+            finally:
+                for sg, h in old.items():
+                    signal.signal(sg, h)
+            if got_line or rc == 0 or attempt == 2 or stopped:  # (stopped: somebody asked THIS process to end -- no second attempt)
                 return rc if rc >= 0 else 128 - rc
             first_rc = rc
             try:

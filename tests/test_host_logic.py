@@ -255,3 +255,39 @@ def test_bench_supervisor_restarts_a_measuring_process_that_died_silently(capfd)
             del os.environ[k]
     finally:
         os.environ.update(saved)
+
+
+def test_bench_supervisor_takes_the_measuring_process_with_it(tmp_path):
+    """Whoever stops `bench.py` stops the measurement: SIGTERM is passed on to the measuring process, and a SIGKILL of the
+    supervisor (a time-out) takes it along too (PR_SET_PDEATHSIG) -- no orphan keeps the GPU busy under the next command."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        pidfile = tmp_path / f"pid{int(sig)}"
+        child = f"import os, time\nopen({str(pidfile)!r}, 'w').write(str(os.getpid()))\ntime.sleep(60)\n"
+        sup = subprocess.Popen([sys.executable, "-c",
+                                f"import sys; sys.path.insert(0, {root!r}); import bench; "
+                                f"sys.exit(bench.supervise_single_rank([sys.executable, '-c', {child!r}]))"],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t0 = time.time()
+        while not (pidfile.exists() and pidfile.read_text()) and time.time() - t0 < 60:
+            time.sleep(0.05)
+        pid = int(pidfile.read_text())
+        sup.send_signal(sig)
+        sup.wait(timeout=30)
+        t0 = time.time()
+        alive = True
+        while alive and time.time() - t0 < 10:
+            try:
+                os.kill(pid, 0)
+                # (a zombie re-parented to init answers kill(0) until it is reaped: look at its state)
+                alive = open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] not in ("Z", "X")
+            except (ProcessLookupError, FileNotFoundError):
+                alive = False
+            time.sleep(0.05)
+        assert not alive, f"the measuring process survived its supervisor's {sig.name}"
