@@ -740,13 +740,15 @@ def _die_with_parent_fn():
 
 
 def supervise_single_rank(cmd=None) -> int:
-    """Run the measurement in a child process and pass its output through.  If the child dies WITHOUT having printed its JSON line
-    (seen twice in this round's ~45 runs, both silently and within half a minute of the start), run it once more; the line of the second attempt carries `"attempts": 2` and how the first one ended.
-    The first occurrence left no trace at all; the second (exit status 1, nothing on stdout or stderr, < 30 s after start) is why
-    ANY unsuccessful exit without a line is retried, and why the measuring process leaves breadcrumbs (`_phase`)."""
-    import subprocess
-
+    """Run the measurement in a child process and pass its output through.  A child that ends unsuccessfully WITHOUT having printed
+    its JSON line is run once more; the line of the second attempt carries `"attempts": 2` and how / where the first one ended
+    (`_phase` breadcrumbs).  History: three default runs of round 5 ended without a line and without a word; the
+    breadcrumbs of this supervisor located the exit (`main.train_one_epoch` stopping on a non-finite loss inside an auxiliary leg,
+    after the replayed-step leg had left non-finite parameters) -- the legs are guarded now and the suspected cause is removed, the
+    supervisor stays as the last line of defence for the one number the driver reads.  Termination requests are passed on and are
+    never answered with a second attempt; the child dies with this process."""
     import signal
+    import subprocess
     import tempfile
     import threading
 
