@@ -79,7 +79,7 @@ def ref_config(cfg):
     )
 
 
-def build_ref_model(deberta, cfg, P):
+def build_ref_model(deberta, cfg, P, ft_ln=True):
     m = deberta.DebertaV2ForMaskedLM(
         ref_config(cfg),
         max_feats=cfg.max_feats,
@@ -87,6 +87,7 @@ def build_ref_model(deberta, cfg, P):
         ds_factor_attn=cfg.ds_factor_attn,
         ds_factor_ff=cfg.ds_factor_ff,
         n_ans=cfg.n_ans,
+        ft_ln=ft_ln,
     )
     sd = m.state_dict()
     missing = [k for k in P if k not in sd]
@@ -373,6 +374,43 @@ def g17_train_mode(deberta, adapter_mod):
     assert abs(ev.loss.item() - out.loss.item()) > 1e-4, "dropout was not live"
     npz("G17_train_mode", gen_seed=np.array([1717]), p_hidden=np.array([0.1]), p_att=np.array([0.1]), p_adapter=np.array([0.1]),
         logits=out.logits, loss=out.loss, **{"in." + k: v for k, v in batch.items()}, **grads)
+
+
+ABLATIONS = [(0, 0, True), (8, 8, False), (0, 8, True), (8, 0, False)]  # (ds_factor_attn, ds_factor_ff, ft_ln)
+
+
+def g18_ablation_flags(deberta):
+    """The reference's ablation switches (args.py:333-337 -> model/deberta.py:252,326: `ds_factor_attn / ds_factor_ff = 0` builds no
+    adapter at that site; :1152-1158: `ft_ln=False` leaves the LayerNorms frozen) on the tiny model, eval mode: which parameters
+    exist, which are trainable, logits, loss and every trainable gradient -- per variant.  Pins the oracle the GPU test
+    test_freeze_policy_flag_variants_vs_oracle compares the HIP path with."""
+    from oracle.deberta_oracle import synth_params
+
+    out = {}
+    for ds_a, ds_f, ft_ln in ABLATIONS:
+        tag = f"a{ds_a}_f{ds_f}_ln{int(ft_ln)}"
+        cfg = _tiny_cfg(ds_factor_attn=ds_a, ds_factor_ff=ds_f)
+        P = synth_params(cfg, seed=61, std=0.05, ln_jitter=0.1)
+        m = build_ref_model(deberta, cfg, P, ft_ln=ft_ln)
+        batch = synth_batch(cfg, B=2, L=13, seed=18)
+        o = m(**batch)
+        o.loss.backward()
+        names = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+        assert names, tag
+        assert any("adapter" in n for n, _ in m.named_parameters()) == bool(ds_a or ds_f), tag
+        out[tag + "/trainable"] = np.array("\n".join(names))
+        out[tag + "/parameters"] = np.array("\n".join(sorted(n for n, _ in m.named_parameters())))
+        out[tag + "/logits_every_4th_column"] = o.logits[..., ::4]  # (fixture size; the loss ties down the rest)
+        out[tag + "/loss"] = o.loss
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None, (tag, n)
+                out[tag + "/grad." + n] = p.grad
+            else:
+                assert p.grad is None, (tag, n)
+        if tag == "a0_f0_ln1":
+            out.update({"in." + k: v for k, v in batch.items()})
+    npz("G18_ablation_flags", **out)
 
 
 def g5c_attentions(deberta):
@@ -926,6 +964,7 @@ def main():
         "G14": lambda: g14_g15_xlarge_downstream(deberta),  # writes G14 and G15
         "G16": lambda: g16_checkpoint(deberta, load_downstream()[2]),
         "G17": lambda: g17_train_mode(deberta, adapter_mod),
+        "G18": lambda: g18_ablation_flags(deberta),
     }
     for k, fn in jobs.items():
         if args.only and k not in args.only.split(","):

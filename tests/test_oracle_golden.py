@@ -301,3 +301,39 @@ def test_bf16_operand_mode_is_opt_in_and_close():
     assert torch.equal(a["logits"], c["logits"])
     err = (a["logits"] - b["logits"]).abs().max().item()
     assert 0 < err < 5e-2, err
+
+
+@pytest.mark.parametrize("ds_a,ds_f,ft_ln", [(0, 0, True), (8, 8, False), (0, 8, True), (8, 0, False)],
+                         ids=["no-adapters", "ft_ln-off", "ffn-adapter-only", "attn-adapter-only+ft_ln-off"])
+def test_g18_ablation_flags_of_the_reference(golden, ds_a, ds_f, ft_ln):
+    """G18: the reference built with its ablation switches (args.py:333-337: ds_factor_attn / ds_factor_ff = 0 -> no adapter at that
+    site, model/deberta.py:252,326; ft_ln=False -> LayerNorms stay frozen, :1152-1158).  The oracle must agree on which parameters
+    exist, which are trainable (`is_trainable(name, ft_ln)` = the reference's substring rule), on logits, loss and every trainable
+    gradient -- it is what the GPU test of the same flags (test_freeze_policy_flag_variants_vs_oracle) compares the HIP path with."""
+    g = golden("G18_ablation_flags", raw=True)
+    tag = f"a{ds_a}_f{ds_f}_ln{int(ft_ln)}"
+    cfg = _tiny_cfg(ds_factor_attn=ds_a, ds_factor_ff=ds_f)
+    P = O.synth_params(cfg, seed=61, std=0.05, ln_jitter=0.1)
+    ref_params = str(g[tag + "/parameters"]).split("\n")
+    ref_train = str(g[tag + "/trainable"]).split("\n")
+    # the reference's decoder.weight is an untied copy under the import shims (SURVEY App. B note 6); everything else by name
+    assert sorted(k for k in P) == sorted(n for n in ref_params if "decoder" not in n)
+    assert sorted(k for k in P if O.is_trainable(k, ft_ln=ft_ln)) == ref_train
+    assert any("adapter" in k for k in P) == bool(ds_a or ds_f)
+    assert any("LayerNorm" in k for k in ref_train) == ft_ln
+    batch = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in.")}
+    for k, v in P.items():
+        v.requires_grad_(O.is_trainable(k, ft_ln=ft_ln))
+    out = O.forward(P, cfg, **batch)
+    assert abs(out["loss"].item() - float(g[tag + "/loss"])) < 1e-5
+    assert maxabs(out["logits"][..., ::4], torch.from_numpy(g[tag + "/logits_every_4th_column"])) < 5e-5
+    out["loss"].backward()
+    n = 0
+    for k, v in P.items():
+        if O.is_trainable(k, ft_ln=ft_ln):
+            ref = torch.from_numpy(g[tag + "/grad." + k])
+            assert maxabs(v.grad, ref) < 1e-4 * max(ref.abs().max().item(), 1e-3), k
+            n += 1
+        else:
+            assert v.grad is None, k
+    assert n == len(ref_train) == len([k for k in g if k.startswith(tag + "/grad.")])
