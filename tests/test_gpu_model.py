@@ -1167,6 +1167,54 @@ def test_graphed_training_step_equals_the_eager_step(set_to_none):
         assert torch.equal(p0[n], p1[n]), n
 
 
+def test_graphed_training_step_soak_300_replays():
+    """model.training_graphs over 300 replayed optimizer steps at the true xlarge dimensions (4 layers, B = 8, S = 138: the real
+    8-phase GEMM / attention / adapter kernels, split GEMM launches with their aux-stream branch included): the flat gradient
+    buffer is finite after EVERY backward replay (counted on the device, read back once per 50 steps so that the replays run
+    back to back as in a training loop) and every 100th replay equals the eager step from the same state bit for bit.  Round 5
+    saw about one non-finite replay in 500 while the zero fills of accumulation targets were memset nodes of the graphs; with
+    kernel-only graphs (fbl_zero) the full-size soak -- tools/soak_graphs.py, 24 layers, B = 32: 6 500 replays, 26 eager
+    comparisons, profiles/r06_soak_graphs*.json -- and this short one are clean.  The step it replays: reference main.py:59-90."""
+    from frozenbilm_amd.optim import FusedAdam
+
+    cfg = O.OracleConfig()
+    cfg.num_hidden_layers = 4
+    cfg.vocab_size = 4096
+    P = O.synth_params(cfg, seed=71)
+    torch.manual_seed(99)
+    m = build(cfg, P, train=True)
+    opt = FusedAdam(m, lr=3e-5, betas=(0.9, 0.95))
+    batch = to_dev(synth_batch(cfg, B=8, L=128, seed=5))
+    m.training_graphs = True
+    n = 300
+    nf = torch.zeros(n, dtype=torch.int32, device=DEV)
+    mism = []
+    for i in range(n):
+        seed_before = m.step_seed
+        opt.zero_grad(set_to_none=False)
+        out = m(**batch)
+        out.loss.backward()
+        g = m.engine().flat_grad
+        nf[i] = (~torch.isfinite(g)).sum() + (~torch.isfinite(out.loss.detach())).to(torch.int32)
+        if i % 100 == 99:
+            g_rep, l_rep = g.clone(), out.loss.detach().clone()
+            m.training_graphs = False
+            m.step_seed = seed_before
+            opt.zero_grad(set_to_none=False)
+            o2 = m(**batch)
+            o2.loss.backward()
+            if not (torch.equal(g_rep, m.engine().flat_grad) and torch.equal(l_rep, o2.loss.detach())):
+                mism.append(i)
+            m.training_graphs = True
+            g.copy_(g_rep)
+        opt.step(clip_max_norm=0.1)
+        if i % 50 == 49:
+            bad = nf[:i + 1].cpu()
+            assert int(bad.sum()) == 0, f"non-finite gradient in replay {int(torch.nonzero(bad)[0])}"
+    assert not mism, mism
+    assert m.__dict__.get("_train_graph_captures", 0) == 1
+
+
 def test_inference_shortcuts_change_nothing():
     """Inference forwards inside model.weights_frozen() keep the per-layer position projections across forwards, reuse the
     key/value projection of the first enhanced-mask-decoder pass in the second and, when only a loss is asked for, run the
