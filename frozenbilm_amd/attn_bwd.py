@@ -1,7 +1,8 @@
 """Host-side orchestration of the disentangled-attention backward (see csrc/attn_bwd.hip for the math).
 
     prep     : D = rowdot(dO, O); K^T, Q^T (head-major [nh,64,B,Sp]); PK^T, PQ^T   (one launch)
-    kernel A : dV, dS, dS^T
+    kernel A : dV, dS, dS^T   (from the probabilities the training forward saved: fbl_disent_attn_bwd_dsp; recomputed
+               by fbl_disent_attn_bwd_ds when there are none -- engine_options["attn_save_p"] = False)
     shear(0) : dQ = dS.K   + G1.PK   (+ G1^T)        shear(1) : dK = dS^T.Q + G2.PQ   (+ G2^T)
     GEMM     : dPK[h] = G1^T[h] . Q^T[h]^T           GEMM     : dPQ[h] = G2^T[h] . K^T[h]^T     (split-K, per head)
 """
@@ -85,8 +86,14 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     # |i-j| < lin: identity buckets, relidx injective (model/deberta.py:578-589: mid = bucket_size // 2)
     lin = eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30
     lin_a = min(lin, span2 // 2) if eng.cfg.position_buckets > 0 else 0  # affine addressing of kernel A: identity buckets only
-    L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
-                         B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)
+    if getattr(sv, "psave", None) is not None:
+        # the training forward saved its probabilities: no recomputation of the scores (fbl_disent_attn_bwd_dsp)
+        L.disent_attn_bwd_dsp(sv.psave, sv.msave, v, dctx, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST, B, S, Sp, nh,
+                              p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, row0=row0)
+        sv.psave = sv.msave = None
+    else:
+        L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
+                             B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)
     # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
     if bufs is None:
         G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)

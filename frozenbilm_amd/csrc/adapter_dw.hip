@@ -44,12 +44,12 @@ struct AdwArgs {
 
 constexpr int WI = 2;             // 16-column MFMA tiles per wave along the wide operand (4: +5 % at Ap = 192, spills at 256)
 constexpr int WT = WI * 32;       // wide columns of a tile
-constexpr int ADW_LDW = WT + 8;   // bf16 row stride of the staged wide tile [64][WT]
+constexpr int ADW_LDW = WT + 16;  // bf16 row stride of the staged wide tile [64][WT]: 40 dwords = 8 x odd (see the fragment reads)
 
 template <int NT, int WHICH>
 __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, const int th, const int o) {
   constexpr int AP = NT * 32;       // narrow columns
-  constexpr int LDS_ = AP + 8;      // bf16 row stride of the staged narrow tile [64][AP]
+  constexpr int LDS_ = AP + 16;     // bf16 row stride of the staged narrow tile [64][AP]: (AP + 16) / 2 dwords = 8 x odd for AP = 64 k
   constexpr int NCH = AP / 8;       // 16-byte chunks per narrow row
   constexpr int SPT = (64 * NCH) / 256;  // narrow chunks per thread (AP = 64 -> 2 ... 256 -> 8)
   constexpr int WCH = WT / 8, WPT = (64 * WCH) / 256;
@@ -120,10 +120,14 @@ __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, c
   float cs[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) cs[j] = 0.f;
-  // fragment read bases of this lane: row (fg*8 + frow/4) of a 32-row half, 4-column sub-block (frow%4) -- everything else
-  // is a compile-time offset
-  const bf16* fW = sW + (fg * 8 + (frow >> 2)) * ADW_LDW + (frow & 3) * 4 + wm * (WI * 16);
-  const bf16* fS = sS + (fg * 8 + (frow >> 2)) * LDS_ + (frow & 3) * 4 + wn * (NT * 16);
+  // fragment read bases of this lane: row (fg*4 + frow/4) of a 32-row half, 4-column sub-block (frow%4) -- everything else
+  // is a compile-time offset.  The k slots of a lane group (8 per MFMA) are rows fg*4 .. fg*4+3 (first read) and 16 + fg*4 ..
+  // (second read) of the half -- the same permutation of the 32 rows for both operands, so the contraction is unchanged.
+  // Why not rows fg*8 .. fg*8+7: ds_read_b64_tr_b16 serves lanes 0-31 (groups 0, 1) in one pass, i.e. eight 32-byte row
+  // pieces; with rows {0-3, 8-11} no row pitch puts them on disjoint banks (r05_pmc.md: 33 % of the LDS cycles of this kernel
+  // were bank conflicts), with the eight CONSECUTIVE rows {0-7} a pitch of 8 x odd dwords tiles the 64 banks exactly.
+  const bf16* fW = sW + (fg * 4 + (frow >> 2)) * ADW_LDW + (frow & 3) * 4 + wm * (WI * 16);
+  const bf16* fS = sS + (fg * 4 + (frow >> 2)) * LDS_ + (frow & 3) * 4 + wn * (NT * 16);
   if (total > 0) load_tile();
   for (int it = 0; it < total; ++it) {
 #pragma unroll
@@ -142,7 +146,7 @@ __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, c
         const bf16* p = fW + s * 32 * ADW_LDW + i * 16;
         union { tr16x4 h[2]; bf16x8 v; } u;
         u.h[0] = lds_tr16(p);
-        u.h[1] = lds_tr16(p + 4 * ADW_LDW);
+        u.h[1] = lds_tr16(p + 16 * ADW_LDW);
         wf[i] = u.v;
       }
 #pragma unroll
@@ -150,7 +154,7 @@ __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, c
         const bf16* p = fS + s * 32 * LDS_ + j * 16;
         union { tr16x4 h[2]; bf16x8 v; } u;
         u.h[0] = lds_tr16(p);
-        u.h[1] = lds_tr16(p + 4 * LDS_);
+        u.h[1] = lds_tr16(p + 16 * LDS_);
         sf[j] = u.v;
       }
       if (WHICH == 1 && do_cs && s == wm) {
@@ -229,7 +233,7 @@ __device__ __forceinline__ void adw_tile(const AdwArgs& g, bf16* sW, bf16* sS, c
 template <int NT>
 __global__ __launch_bounds__(256, 2) void adapter_dw_kernel(AdwArgs g) {
   __shared__ __attribute__((aligned(16))) bf16 sW[64 * ADW_LDW];
-  __shared__ __attribute__((aligned(16))) bf16 sS[64 * (NT * 32 + 8)];
+  __shared__ __attribute__((aligned(16))) bf16 sS[64 * (NT * 32 + 16)];
   // Workgroup -> (problem, tile column).  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
   // its own L2; all tile columns of one problem (adapter, which) read the SAME narrow operand, so they are given to one XCD
   // (problem p lives on XCD p % 8): the narrow rows are fetched from memory once instead of once per XCD (measured before:

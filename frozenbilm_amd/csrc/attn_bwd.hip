@@ -466,6 +466,189 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- kernel A, P saved by the forward
+// The training forward (attn_fwd.hip, SAVEP) leaves the un-normalised probabilities of every visited tile pair in HBM --
+// psave[b,h,i,j] = exp2(k2*(s_ij - m)), bf16, with m the running row maximum at key tile j/64 (msave) -- so this pass does
+// not repeat Q.K^T, the two bias GEMMs against the position-table windows and the LDS gather (kernel A above: 28 of its 44
+// MFMA pairs, ten fp16 tile stores, 32 element reads per lane and a barrier per tile pair; 288 GB of HBM hold the 157 MB
+// per layer execution easily):  P_ij = psave_ij * exp2(msave_i - lse_i*log2(e)).  Everything after P is kernel A's:
+// dP = dO.V^T through the regenerated dropout mask, dS = P*(dP - D)*scale, dV += drop(P)^T.dO, dS and dS^T staged through
+// LDS.  Two barriers per tile pair, 37 KiB of LDS, no index table, no position tables.
+struct BwdPArgs {
+  const bf16* psave; const float* msave;
+  const bf16* v; long ldv;
+  const bf16* dO; long ldo;
+  const int32_t* klen; const int32_t* border;
+  const float* lse; const float* Dv;  // [B,nh,S]
+  float scale, p_drop; uint64_t seed; const uint64_t* seed_dev;
+  bf16* dV; long lddv;
+  bf16* dS; bf16* dST;                // [B,nh,Sp,Sp]
+  int B, S, Sp, nh;
+  const int32_t* row0;                // packed-row layout of v / dO / dV or null
+};
+constexpr int LDP = 80;                     // bf16 row stride of the P tile: 40 dwords = 8 x odd -> the eight consecutive rows a
+                                            // ds_read_b64_tr_b16 pass touches (lanes 0-31: 32 bytes each) tile the 64 banks
+constexpr int P_DOS = 0;                    // [64 i][64] bf16 swizzled
+constexpr int P_PS = P_DOS + 8192;          // [64 i][LDP] bf16
+constexpr int P_ST = P_PS + 64 * LDP * 2;   // dS staging [64 i][LDV]
+constexpr int P_STT = P_ST + 64 * LDV * 2;  // dS^T staging [64 j][LDV]
+constexpr int P_ROW = P_STT + 64 * LDV * 2; // float f[64], D[64]
+constexpr int P_TOTAL = P_ROW + 512;
+
+struct PTileRegs {
+  bf16x8 d[2], p[2];
+  float f, D;
+};
+
+template <bool PACKED = false>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dsp_kernel(BwdPArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, Sp = a.Sp;
+  const WgCoord wc = wg_coord(Sp / 64, a.nh, a.B, a.border);
+  const int j0 = wc.x * 64, h = wc.h, b = wc.b;
+  const int j = j0 + w * 16 + c;  // this lane's key
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;
+  const int jc = min(j, lim - 1);
+  float* rF = (float*)(smem + P_ROW);
+  float* rD = rF + 64;
+  bf16* dst = (bf16*)(smem + P_ST);    // dS tile [query][key]
+  bf16* dstT = (bf16*)(smem + P_STT);  // dS^T tile [key][query]
+
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;
+  const int srow = tid >> 3, sch = tid & 7;
+  const int fb0 = c * 128 + ((g ^ (c & 7)) << 4), fb1 = fb0 ^ 64;  // dO fragment of row x*16 + c: + x*2048
+  const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);           // dO staging slot of row srow + 32 t: + t*4096
+  const int sp = srow * (LDP * 2) + sch * 16;                      // P staging slot: + t*32*LDP*2
+
+  bf16x8 vf[2];
+  {
+    const long off = (rb + jc) * a.ldv + h * 64 + g * 8;
+    vf[0] = *(const bf16x8*)(a.v + off);
+    vf[1] = *(const bf16x8*)(a.v + off + 32);
+  }
+  f32x4 dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const DropKey dk = attn_drop_key(a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0, b * a.nh + h, a.p_drop);
+  const long sbase = ((long)b * a.nh + h) * Sp * Sp;
+  const float* mrow = a.msave + (((long)b * a.nh + h) * (Sp >> 6) + wc.x) * S;
+
+  auto load_tile = [&](int it, PTileRegs& R) {
+    const int i0 = it * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int il = i0 + srow + t * 32;
+      R.d[t] = *(const bf16x8*)(a.dO + (rb + min(il, lim - 1)) * a.ldo + h * 64 + sch * 8);
+      R.p[t] = *(const bf16x8*)(a.psave + sbase + (long)il * Sp + j0 + sch * 8);
+    }
+    R.f = 0.f; R.D = 0.f;  // padding and masked queries: lse = +inf in the forward -> P = 0
+    if (tid < 64) {
+      const int i = i0 + tid;
+      if (i < lim) {
+        const long o = ((long)b * a.nh + h) * S + i;
+        const float l = a.lse[o];
+        R.f = (l < INFINITY) ? __builtin_amdgcn_exp2f(mrow[i] - l * LOG2E) : 0.f;
+        R.D = a.Dv[o];
+      }
+    }
+  };
+  auto store_tile = [&](const PTileRegs& R) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      *(bf16x8*)(smem + P_DOS + sb + t * 4096) = R.d[t];
+      *(bf16x8*)(smem + P_PS + sp + t * (32 * LDP * 2)) = R.p[t];
+    }
+    if (tid < 64) {
+      rF[tid] = R.f;
+      rD[tid] = R.D;
+    }
+  };
+
+  PTileRegs R;
+  if (nqt > 0) load_tile(0, R);
+  for (int it = 0; it < nqt; ++it) {
+    const int i0 = it * 64;
+    store_tile(R);
+    __syncthreads();  // (also: every wave is done with the staging tiles of the previous pair)
+    if (it + 1 < nqt) load_tile(it + 1, R);  // the next pair's operands fly during this pair's arithmetic
+
+    bf16x4 dsb[4], pfh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      // P~ of queries nt*16 + g*4 + {0..3}, key column c: the transposing read hands each lane its column of a [4 x 16] block
+      union { tr16x4 t; bf16x4 v; } pu;
+      pu.t = lds_tr16((const bf16*)(smem + P_PS + (nt * 16 + g * 4 + (c >> 2)) * (LDP * 2) + (w * 16 + (c & 3) * 4) * 2));
+      const f32x4 f4 = *(const f32x4*)(rF + nt * 16 + g * 4);
+      const f32x4 d4 = *(const f32x4*)(rD + nt * 16 + g * 4);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + P_DOS + nt * 2048 + fb0), vf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + P_DOS + nt * 2048 + fb1), vf[1], acc, 0, 0, 0);
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          uint32_t x, y;
+          attn_drop_block(dk, (i0 + nt * 16 + g * 4 + bb * 2) >> 1, j >> 1, Sp >> 1, &x, &y);
+          keep[bb * 2] = attn_drop_keep(dk, x, y, 0, j & 1);
+          keep[bb * 2 + 1] = attn_drop_keep(dk, x, y, 1, j & 1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = f4[r] != 0.f ? bf2f(pu.v[r]) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
+        dsb[nt][r] = f2bf(pv * (acc[r] * keep[r] - d4[r]) * a.scale);
+        pfh[nt][r] = f2bf(pv * keep[r]);
+      }
+    }
+    // ---- dV^T += dO^T . drop(P):  k-slot e of step kk <-> query kk*32 + (e>>2)*16 + g*4 + (e&3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = pfh[2 * kk][e];
+        pf[4 + e] = pfh[2 * kk + 1][e];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int r = g * 4 + (c >> 2);
+        const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        const char* db = smem + P_DOS + r * 128 + ((ch ^ (r & 7)) << 4) + sub;
+        union { tr16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = lds_tr16((const bf16*)(db + kk * 4096));
+        u.h[1] = lds_tr16((const bf16*)(db + kk * 4096 + 2048));
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, dv[dt], 0, 0, 0);
+      }
+    }
+    // ---- dS and dS^T leave through LDS transposes: 16-byte rows
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      *(bf16x4*)(dstT + (w * 16 + c) * LDV + nt * 16 + g * 4) = dsb[nt];  // [key][query]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(nt * 16 + g * 4 + r) * LDV + w * 16 + c] = dsb[nt][r];  // [query][key]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = srow + t * 32;
+      *(bf16x8*)(a.dS + sbase + (long)(i0 + row) * Sp + j0 + sch * 8) = *(const bf16x8*)(dst + row * LDV + sch * 8);
+      *(bf16x8*)(a.dST + sbase + (long)(j0 + row) * Sp + i0 + sch * 8) = *(const bf16x8*)(dstT + row * LDV + sch * 8);
+    }
+  }
+
+  if (j < lim) {
+    bf16* op = a.dV + (rb + j) * a.lddv + h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
+  }
+}
+
 // ------------------------------------------------------------------------------------------- kernel BC
 struct ShearArgs {
   const bf16* X;                          // dS (NEG=0) or dS^T (NEG=1): [B,nh,Sp,Sp], rows = output rows
@@ -754,6 +937,33 @@ extern "C" int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* 
     hipLaunchKernelGGL(attn_bwd_ds_kernel<true>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_ds_kernel<false>, grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_disent_attn_bwd_dsp(const void* psave, const float* msave, const void* v, int64_t ldv, const void* dO,
+                                       int64_t ldo, const int32_t* klen, const int32_t* border, const float* lse, const float* Dv,
+                                       float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv,
+                                       void* dS, void* dST, int B, int S, int Sp, int nh, const int32_t* row0, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if ((ldv % 8) || (ldo % 8) || (lddv % 4)) return FBL_ERR_ALIGN;
+  if (!psave || !msave || !v || !dO || !lse || !Dv || !dV || !dS || !dST) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
+  if (B <= 0 || nh <= 0) return 0;
+  BwdPArgs a{(const bf16*)psave, msave, (const bf16*)v, ldv, (const bf16*)dO, ldo, klen, border, lse, Dv, scale, p_drop, seed,
+             seed_dev, (bf16*)dV, lddv, (bf16*)dS, (bf16*)dST, B, S, Sp, nh, row0};
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dsp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dsp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(Sp / 64) * nh * B);
+  if (row0)
+    hipLaunchKernelGGL(attn_bwd_dsp_kernel<true>, grid, dim3(256), P_TOTAL, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dsp_kernel<false>, grid, dim3(256), P_TOTAL, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

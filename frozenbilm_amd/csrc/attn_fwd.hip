@@ -39,6 +39,11 @@ struct AttnArgs {
   int dbg;  // ablation switches (FBL_ATTN_DBG of debug builds; compiled out of the product library)
   const int32_t* row0;  // [B+1] packed-row layout (PACKED kernels): sample b owns activation rows [row0[b], row0[b+1]) =
                         // its positions 0 .. row0[b+1]-row0[b]-1; null = the padded [B, S] grid (row b*S + s)
+  // SAVEP kernels (training): what the backward would otherwise recompute -- psave[b,h,i,j] = exp2(k2*(s_ij - m)) (bf16,
+  // [B,nh,Sp,Sp], BEFORE dropout) with m the running row maximum at key tile j/64, and msave[b,h,j/64,i] = k2*m (fp32,
+  // [B,nh,Sp/64,S]): P_ij = psave * exp2(msave - lse*log2(e)).  Only the tile pairs the forward visits are written.
+  bf16* psave;
+  float* msave;
 };
 #ifdef FBL_DEBUG_SWITCHES
 #define ATTN_DBG(bit) (a.dbg & (bit))
@@ -71,7 +76,7 @@ struct TileRegs {  // one key tile in flight: 4 x 16 B per thread
 
 // PACKED: q / k / v / ctx rows follow AttnArgs::row0 (ragged batches without their padding rows); mask and lse keep the
 // padded [B, S] indexing.  A separate instantiation: the padded kernel's code is unchanged.
-template <int OCC, bool PF, bool PACKED = false>
+template <int OCC, bool PF, bool PACKED = false, bool SAVEP = false>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -295,6 +300,15 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if constexpr (SAVEP) {
+      // the un-normalised probabilities of this pair leave as they are (4 consecutive keys = 8 bytes per lane and key group;
+      // padding query rows i < Sp exist in the buffer and may receive garbage: their lse is +inf, the backward reads P = 0)
+      bf16* pp = a.psave + (((long)b * a.nh + h) * Sp + i) * Sp + j0 + g * 4;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        *(bf16x4*)(pp + nt * 16) = (bf16x4){f2bf(p[nt * 4]), f2bf(p[nt * 4 + 1]), f2bf(p[nt * 4 + 2]), f2bf(p[nt * 4 + 3])};
+      if (g == 0 && i < S) a.msave[(((long)b * a.nh + h) * (Sp >> 6) + jt) * S + i] = m_new * k2;
+    }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
     if (a.p_drop > 0.f && !ATTN_DBG(8)) {
@@ -406,13 +420,15 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
                                    const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                                    const int32_t* border, float scale, float p_drop, uint64_t seed,
                                    const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
-                                   int lin_span, const int32_t* row0, void* stream) {
+                                   int lin_span, const int32_t* row0, void* psave, float* msave, void* stream) {
   if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldp % 8) || (ldo % 4)) return FBL_ERR_ALIGN;
   if (lin_span < 0 || 2 * lin_span > span2) return FBL_ERR_ARG;  // idx(0) +- (lin_span - 1 + 79) must stay inside the table
   if (row0 && !klen) return FBL_ERR_ARG;  // the packed layout is defined by the samples' lengths
+  if ((psave != nullptr) != (msave != nullptr) || (psave && !lse)) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, seed_dev, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0, row0};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)pk, (const bf16*)pq, ldq, ldk, ldp, ldv, relidx, mask, klen, border, scale, p_drop, seed, seed_dev, (bf16*)ctx, ldo, lse, B, S, Sp, nh, span2, lin_span, 0, row0,
+             (bf16*)psave, msave};
   static const int dbg = FBL_ENV_INT("FBL_ATTN_DBG", 0);
   a.dbg = dbg;
   attn_debug_init();
@@ -424,12 +440,20 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem_bytes;
   }
   dim3 grid((unsigned)((S + 63) / 64) * nh * B);
-  if (row0)
+  if (row0 && psave)
+    hipLaunchKernelGGL((attn_fwd_kernel<3, false, true, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else if (row0)
     hipLaunchKernelGGL((attn_fwd_kernel<3, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+  else if (psave)
+    hipLaunchKernelGGL((attn_fwd_kernel<3, false, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<3, false>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();

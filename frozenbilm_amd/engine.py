@@ -130,6 +130,9 @@ class Engine:
         self.use_side_stream = bool(o.get("side_stream", True))
         self.fold_dx = bool(o.get("fold_dx", True))
         self.dw_on_side = bool(o.get("dw_on_side", False))
+        #   attn_save_p    False = the attention backward recomputes the probabilities (rounds 1-5) instead of reading the ones the
+        #                  training forward saved (157 MB per layer execution at the bench shape, held until the backward)
+        self.attn_save_p = bool(o.get("attn_save_p", True))
         self.fuse_tail = bool(o.get("fuse_tail", True))
         L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(o.get("dw_group", 16))))  # adapter gradient products per launch (<= 16)
@@ -730,10 +733,17 @@ class Engine:
         ctx = torch.empty(N, H, dtype=BF16, device=dev)
         lse = torch.empty(B, nh, S, dtype=F32, device=dev)
         sv.seed_att = run.next_seed() if run.p_att > 0 else 0
+        # training: the forward leaves its un-normalised probabilities (bf16, 157 MB per execution at the bench shape; only the
+        # tile pairs it visits are written) so that the backward does not recompute the scores (attn_bwd.hip, kernel A / dsp)
+        psave = msave = None
+        if run.save and self.attn_save_p:
+            psave = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
+            msave = torch.empty(B, nh, Sp // 64, S, dtype=F32, device=dev)
         L.disent_attn_fwd(qkv[:N, :H], qkv[:N, H:2 * H], qkv[:N, 2 * H:], pk, pq, self.relidx(S), run.mask_i32,
                           1.0 / math.sqrt(64 * 3), ctx, lse, B, S, Sp, nh, self.span2, p_drop=run.p_att,
                           seed=sv.seed_att, klen=run.klen, border=run.border, lin=self.lin_span,
-                          row0=run.pk.row0 if run.pk is not None else None)
+                          row0=run.pk.row0 if run.pk is not None else None, psave=psave, msave=msave)
+        sv.psave, sv.msave = psave, msave
         if getattr(run, "want_attn", False) and q is None:
             # output_attentions=True: the encoder layers' probabilities (model/deberta.py:544-560; the enhanced-mask-decoder
             # passes are called with return_att=False, :1395-1408), materialised by a plain kernel from the stored lse
@@ -1379,6 +1389,8 @@ class LayerSave:
     seed_ad2: int = 0
     seed_ln1: int = 0
     seed_ln2: int = 0
+    psave: torch.Tensor = None
+    msave: torch.Tensor = None
 
 
 @dataclass

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
+ABI_VERSION = 7  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -51,12 +51,14 @@ SIGNATURES = {
     "fbl_colsum": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "fbl_head_transpose": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _vp]),
     "fbl_disent_attn_fwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l,
-                                 _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+                                 _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_disent_attn_bwd_dsp": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l, _vp, _vp,
+                                     _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp, _vp, _vp]),
     "fbl_gt_tilemask": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -508,7 +510,13 @@ def _row0(row0, B, klen):
 
 
 def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh, span2, p_drop=0.0, seed=0, klen=None,
-                    border=None, lin=0, row0=None):
+                    border=None, lin=0, row0=None, psave=None, msave=None):
+    """psave bf16 [B,nh,Sp,Sp] + msave fp32 [B,nh,Sp/64,S] (training): the forward leaves its un-normalised probabilities
+    for fbl_disent_attn_bwd_dsp (include/fbl.h)"""
+    if psave is not None:
+        _req(psave, torch.bfloat16, "psave"); _req(msave, torch.float32, "msave")
+        assert psave.is_contiguous() and msave.is_contiguous()
+        assert psave.numel() == B * nh * Sp * Sp and msave.numel() == B * nh * (Sp // 64) * S
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (pk, "pk"), (pq, "pq"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(relidx, torch.int16, "relidx"); _req(mask, torch.int32, "mask")
@@ -517,7 +525,8 @@ def disent_attn_fwd(q, k, v, pk, pq, relidx, mask, scale, ctx, lse, B, S, Sp, nh
     assert _rows2d(pq, "pq") == ldp
     _chk(load().fbl_disent_attn_fwd(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pk), _p(pq), ldp, _p(relidx),
                                     _p(mask), _p(klen), _p(border), float(scale), float(p_drop), int(seed), _seed_dev(), _p(ctx), ldo,
-                                    _p(lse), B, S, Sp, nh, span2, int(lin), _row0(row0, B, klen), _stream()), "fbl_disent_attn_fwd")
+                                    _p(lse), B, S, Sp, nh, span2, int(lin), _row0(row0, B, klen), _p(psave), _p(msave), _stream()),
+         "fbl_disent_attn_fwd")
 
 
 def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
@@ -558,6 +567,18 @@ def disent_attn_bwd_ds(q, k, v, dO, pk, pq, relidx, mask, lse, Dv, scale, dV, dS
                                        _p(relidx), _p(mask), _p(klen), _p(border), _p(lse), _p(Dv), float(scale), float(p_drop), int(seed), _seed_dev(),
                                        _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, span2, int(lin), _row0(row0, B, klen), _stream()),
          "fbl_disent_attn_bwd_ds")
+
+
+def disent_attn_bwd_dsp(psave, msave, v, dO, lse, Dv, scale, dV, dS, dST, B, S, Sp, nh, p_drop=0.0, seed=0, klen=None,
+                        border=None, row0=None):
+    """kernel A of the attention backward from the probabilities the training forward saved (no recomputation of the scores)"""
+    _req(psave, torch.bfloat16, "psave"); _req(msave, torch.float32, "msave")
+    assert psave.is_contiguous() and msave.is_contiguous()
+    assert psave.numel() == B * nh * Sp * Sp and msave.numel() == B * nh * (Sp // 64) * S
+    ldv, ldo, lddv = _rows2d(v, "v"), _rows2d(dO, "dO"), _rows2d(dV, "dV")
+    _chk(load().fbl_disent_attn_bwd_dsp(_p(psave), _p(msave), _p(v), ldv, _p(dO), ldo, _p(klen), _p(border), _p(lse), _p(Dv),
+                                        float(scale), float(p_drop), int(seed), _seed_dev(), _p(dV), lddv, _p(dS), _p(dST),
+                                        B, S, Sp, nh, _row0(row0, B, klen), _stream()), "fbl_disent_attn_bwd_dsp")
 
 
 def gt_tilemask(relidx, klen, B, S, Sp, span2, neg, rmin, rcnt):

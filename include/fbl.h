@@ -249,12 +249,17 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
  *   written).  mask, lse and the scratch tensors of the backward keep their padded [B, S(p)] indexing.  The rows that
  *   exist receive exactly the values of the padded layout.  The same argument on the three backward entry points below
  *   (fbl_attn_bwd_prep: q / k / dO / O; fbl_disent_attn_bwd_ds: q / k / v / dO / dV; fbl_disent_attn_bwd_shear: out).
+ *   psave / msave (optional, both or neither; training): the forward also leaves what the backward would otherwise
+ *   recompute -- psave bf16 [B,nh,Sp,Sp]: psave[b,h,i,j] = exp2(k2*(s_ij - m)) with s the unscaled score, k2 = scale*log2(e)
+ *   and m the running row maximum when key tile j/64 was processed (BEFORE dropout; exactly 0 for masked keys); msave fp32
+ *   [B,nh,Sp/64,S]: msave[b,h,j/64,i] = k2*m.  P_ij = psave_ij * exp2(msave - lse_i*log2(e)).  Only the tile pairs the forward
+ *   visits (both tile indices below ceil(klen/64)) are written -- fbl_disent_attn_bwd_dsp reads exactly those.
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
 int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                         const void* pk, const void* pq, int64_t ldp, const int16_t* relidx,
                         const int32_t* mask, const int32_t* klen, const int32_t* border, float scale, float p_drop,
                         uint64_t seed, const uint64_t* seed_dev, void* ctx, int64_t ldo, float* lse, int B, int S, int Sp, int nh, int span2,
-                        int lin_span, const int32_t* row0, void* stream);
+                        int lin_span, const int32_t* row0, void* psave, float* msave, void* stream);
 
 /* The attention probabilities of fbl_disent_attn_fwd, materialised on request (output_attentions=True; never on the hot
  * path): probs[b, h, i, j] fp32 [B, nh, S, S] = exp(score[i,j] - lse[b,h,i]) with the lse the fused forward stored, exactly 0
@@ -300,6 +305,13 @@ int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t 
                            const int32_t* border, const float* lse, const float* Dv,
                            float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B,
                            int S, int Sp, int nh, int span2, int lin_span, const int32_t* row0, void* stream);
+/* fbl_disent_attn_bwd_ds without the recomputation: P comes from the psave / msave a training forward left (see
+ * fbl_disent_attn_fwd); same outputs (dV, dS, dS^T), same dropout mask (seed), q / k / position tables not needed.
+ * ref: autograd of model/deberta.py:789-818 (softmax, dropout, context), XSoftmax.backward :134-138, XDropout.backward :185-190. */
+int fbl_disent_attn_bwd_dsp(const void* psave, const float* msave, const void* v, int64_t ldv, const void* dO, int64_t ldo,
+                            const int32_t* klen, const int32_t* border, const float* lse, const float* Dv, float scale,
+                            float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST,
+                            int B, int S, int Sp, int nh, const int32_t* row0, void* stream);
 int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb, int64_t y_sd,
                               const void* PT, const int16_t* relidx, const int32_t* klen, const int32_t* border,
                               void* out, int64_t ldout,

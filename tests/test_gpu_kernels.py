@@ -645,13 +645,20 @@ def _border(klen):
     return torch.argsort(klen, descending=True, stable=True).to(torch.int32).contiguous()
 
 
-def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None, border=None, lin=128):
+def _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=0.0, seed=0, klen=None, border=None, lin=128, save_p=None):
+    """save_p: a list that receives (psave, msave) -- the training forward's saved probabilities, allocated NaN-filled so that
+    anything the backward reads without the forward having written it shows up"""
     H = nh * 64
     Sp = (S + 63) // 64 * 64
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.empty(B, nh, S, device=DEV)
+    ps = ms = None
+    if save_p is not None:
+        ps = torch.full((B, nh, Sp, Sp), float("nan"), dtype=BF16, device=DEV)
+        ms = torch.full((B, nh, Sp // 64, S), float("nan"), dtype=torch.float32, device=DEV)
+        save_p[:] = [ps, ms]
     L.disent_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], pqk[:, H:], pqk[:, :H], relidx, mask.view(-1), 1 / math.sqrt(192), ctx,
-                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen, border=border, lin=lin)
+                      lse, B, S, Sp, nh, pqk.shape[0], p_drop=p_drop, seed=seed, klen=klen, border=border, lin=lin, psave=ps, msave=ms)
     return ctx, lse
 
 
@@ -699,8 +706,12 @@ def test_attention_fwd_dropout_rate(L):
     assert ctx.float().std().item() > 1e-3  # not all ones: dropout really dropped something
 
 
+@pytest.mark.parametrize("saved_p", [False, True], ids=["recompute", "saved_p"])
 @pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1), (4, 200, 2)])
-def test_attention_bwd(L, B, S, nh):
+def test_attention_bwd(L, B, S, nh, saved_p):
+    """saved_p: kernel A reads the un-normalised probabilities the (training) forward left in HBM (fbl_disent_attn_bwd_dsp)
+    instead of recomputing the scores; the forward then runs with the same klen / border as the backward (it writes exactly
+    the tile pairs the backward reads -- the buffers start NaN-filled)."""
     from frozenbilm_amd.attn_bwd import disent_attn_bwd
 
     qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=20 + S)
@@ -711,7 +722,9 @@ def test_attention_bwd(L, B, S, nh):
         mask[1, 200:] = 0
     qkv = (qkv.float() * 0.5).to(BF16)
     pqk = (pqk.float() * 0.5).to(BF16)
-    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh)
+    klen_t = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
+    saved = [] if saved_p else None
+    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, klen=klen_t, save_p=saved)
     dctx = bf(rnd(B * S, H, seed=5)).to(BF16)
     # reference grads by autograd
     qkvf = qkv.float().requires_grad_(True)
@@ -731,11 +744,13 @@ def test_attention_bwd(L, B, S, nh):
     import types as _t
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
-    run.klen = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
+    run.klen = klen_t
     run.border = _border(run.klen) if (run.klen is not None and B >= 3) else None  # longest-first dispatch (XCD-aware map at B=4)
     import frozenbilm_amd.attn_bwd as AB
     AB.POISON_GT = True  # unwritten G^T blocks hold NaN: the position-table GEMMs must skip exactly those
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, 0
+    if saved_p:
+        sv.psave, sv.msave = saved
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
     dpqk = torch.zeros(pqk.shape[0], 2 * H, dtype=BF16, device=DEV)
     disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk)
@@ -748,7 +763,7 @@ def test_attention_bwd(L, B, S, nh):
     close(dpqk[:, :H], pqkf.grad[:, :H], 3e-2, 2e-2 * sp, "dPQ")
 
 
-def _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p_att, seed):
+def _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p_att, seed, saved=None):
     from frozenbilm_amd.attn_bwd import disent_attn_bwd
     import types as _t
 
@@ -762,13 +777,16 @@ def _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p_att
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), p_att
     run.klen = None
     sv.qkv, sv.pqk, sv.ctx, sv.lse, sv.seed_att = qkv, pqk, ctx, lse, seed
+    if saved:
+        sv.psave, sv.msave = saved
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
     dpqk = torch.zeros(pqk.shape[0], 2 * H, dtype=BF16, device=DEV)
     disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk)
     return dqkv, dpqk
 
 
-def test_attention_dropout_mask_fwd_bwd_agree(L):
+@pytest.mark.parametrize("saved_p", [False, True], ids=["recompute", "saved_p"])
+def test_attention_dropout_mask_fwd_bwd_agree(L, saved_p):
     """V = I and dO = I expose the dropped-out probability matrix in both directions: forward ctx = drop(P), backward
     dV = drop(P)^T -- the two kernels must regenerate the SAME mask; its statistics must look like iid Bernoulli(1-p)."""
     B, S, nh, p = 2, 64, 2, 0.1
@@ -777,8 +795,9 @@ def test_attention_dropout_mask_fwd_bwd_agree(L):
     qkv = (qkv.float() * 0.3).to(BF16)  # mild scores: every P entry is well above bf16 underflow
     eye = torch.eye(64, device=DEV).repeat(B, nh).to(BF16)  # V[b*S+s, h*64+d] = (s == d)
     qkv[:, 2 * H:] = eye
-    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=1234)
-    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, eye.clone(), mask, relidx, B, S, nh, H, p, 1234)
+    saved = [] if saved_p else None
+    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=1234, save_p=saved)
+    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, eye.clone(), mask, relidx, B, S, nh, H, p, 1234, saved=saved)
     Pf = heads(ctx.float(), B, S, nh)                 # [B,nh,S(query),64(key)]
     Pb = heads(dqkv[:, 2 * H:].float(), B, S, nh)     # [B,nh,S(key),64(query)]
     assert torch.equal(Pf == 0, Pb.transpose(-1, -2) == 0)
@@ -798,21 +817,23 @@ def test_attention_dropout_mask_fwd_bwd_agree(L):
     assert not torch.equal(drop[0, 0], drop[0, 1]) and not torch.equal(drop[0, 0], drop[1, 0])
 
 
-def test_attention_dropout_bwd_linearity(L):
+@pytest.mark.parametrize("saved_p", [False, True], ids=["recompute", "saved_p"])
+def test_attention_dropout_bwd_linearity(L, saved_p):
     """multi-tile, ragged: ctx is linear in V for a fixed mask, so <ctx, dO> == <V, dV> iff backward uses the forward mask."""
     B, S, nh, p = 2, 150, 2, 0.1
     qkv, pqk, mask, relidx, H = _attn_inputs(B, S, nh, seed=78)
     qkv = (qkv.float() * 0.5).to(BF16)
-    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=99)
+    saved = [] if saved_p else None
+    ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, p_drop=p, seed=99, save_p=saved)
     dctx = bf(rnd(B * S, H, seed=6)).to(BF16)
-    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 99)
+    dqkv, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 99, saved=list(saved) if saved else None)
     for h in range(nh):
         sl = slice(h * 64, (h + 1) * 64)
         lhs = (ctx[:, sl].float() * dctx[:, sl].float()).sum().item()
         rhs = (qkv[:, 2 * H:][:, sl].float() * dqkv[:, 2 * H:][:, sl].float()).sum().item()
         assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), 10.0), (h, lhs, rhs)
     # wrong seed in backward breaks the identity by far more than the tolerance
-    dq2, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 100)
+    dq2, _ = _attn_bwd_call(L, qkv, pqk, ctx, lse, dctx, mask, relidx, B, S, nh, H, p, 100, saved=saved)
     assert (dq2[:, 2 * H:].float() - dqkv[:, 2 * H:].float()).abs().max().item() > 1e-2
 
 

@@ -68,6 +68,20 @@ def fwd():
                       seed=7, border=border, lin=LIN)
 
 
+psave = torch.zeros(B, nh, Sp, Sp, dtype=torch.bfloat16, device=dev)
+msave = torch.zeros(B, nh, Sp // 64, S, device=dev)
+
+
+def fwd_save():  # the training forward: also leaves the un-normalised probabilities for the backward
+    L.disent_attn_fwd(q, k, v, pk, pq, relidx, mask.view(-1), scale, ctx, lse, B, S, Sp, nh, span2, klen=klen, p_drop=P,
+                      seed=7, border=border, lin=LIN, psave=psave, msave=msave)
+
+
+def bwd_p():  # kernel A from the saved probabilities
+    L.disent_attn_bwd_dsp(psave, msave, v, dctx, lse, Dv, scale, dqkv[:, 2 * H:], dS, dST, B, S, Sp, nh, p_drop=P, seed=7,
+                          klen=klen, border=border)
+
+
 def prep():
     if os.environ.get("PREP_SPLIT") == "1":  # the five separate launches the fused preparation replaced
         L.attn_rowdot(dctx, ctx, Dv, B, S, nh)
@@ -121,10 +135,11 @@ def shear_both():  # the two shear passes are independent: second one on a side 
     torch.cuda.current_stream().wait_event(ev1)
 
 
-fwd()
+fwd_save()
 prep()
-res = {n: timeit(f) for n, f in (("fwd", fwd), ("prep", prep), ("bwd_a", bwd_a), ("shear0", shear0), ("shear1", shear1),
-                                 ("shear0||1", shear_both))}
+res = {n: timeit(f) for n, f in (("fwd", fwd), ("fwd_save", fwd_save), ("prep", prep), ("bwd_a", bwd_a), ("bwd_p", bwd_p),
+                                 ("shear0", shear0), ("shear1", shear1), ("shear0||1", shear_both))}
 npairs = int(sum(((int(k) + 63) // 64) ** 2 for k in klen.tolist()) * nh)
 tag = f"pairs={npairs} order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
-print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total {sum(res.values()) - res['fwd'] - res['shear0||1']:.1f}us")
+print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total (recompute) {res['prep'] + res['bwd_a'] + res['shear0'] + res['shear1']:.1f}us, (saved P) "
+      f"{res['prep'] + res['bwd_p'] + res['shear0'] + res['shear1']:.1f}us")
