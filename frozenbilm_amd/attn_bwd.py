@@ -3,8 +3,10 @@
     prep     : D = rowdot(dO, O); K^T, Q^T (head-major [nh,64,B,Sp]); PK^T, PQ^T   (one launch)
     kernel A : dV, dS, dS^T   (from the probabilities the training forward saved: fbl_disent_attn_bwd_dsp; recomputed
                by fbl_disent_attn_bwd_ds when there are none -- engine_options["attn_save_p"] = False)
-    shear(0) : dQ = dS.K   + G1.PK   (+ G1^T)        shear(1) : dK = dS^T.Q + G2.PQ   (+ G2^T)
-    GEMM     : dPK[h] = G1^T[h] . Q^T[h]^T           GEMM     : dPQ[h] = G2^T[h] . K^T[h]^T     (split-K, per head)
+    shear(0) : dQ = dS.K   + G1.PK                   shear(1) : dK = dS^T.Q + G2.PQ
+    pos_grad : dPK[h] = sum_b G1^T.Q , dPQ[h] = sum_b G2^T.K -- straight from dS / dS^T (fbl_attn_pos_grad: the sheared operand
+               G is formed on the fly out of LDS); engine_options["pos_grad_gt"] = True keeps the route of rounds 1-5 (the shear
+               passes write G^T, two split-K GEMMs per table contract it against Q^T / K^T)
 """
 from __future__ import annotations
 
@@ -31,6 +33,28 @@ def _relidx_range(S, cfg):
         rv = rel_index_vector(S, cfg.position_buckets, cfg.max_rel, cfg.att_span)
         _RANGE[key] = (int(rv[0]), int(rv[-1]) - int(rv[0]) + 1)
     return _RANGE[key]
+
+
+_DRANGE = {}
+
+
+def _delta_ranges(S, cfg, dev):
+    """(dlo, dcnt, max dcnt): int16 device tensors [rcnt]: table row rmin + r collects the deltas [dlo[r], dlo[r] + dcnt[r]) -- the inverse
+    of the (monotone) relative-index vector, computed once per sequence length"""
+    key = (S, cfg.position_buckets, cfg.max_rel, cfg.att_span, str(dev))
+    if key not in _DRANGE:
+        import numpy as np
+
+        from .model.relpos import rel_index_vector
+
+        rv = np.asarray(rel_index_vector(S, cfg.position_buckets, cfg.max_rel, cfg.att_span), dtype=np.int64)
+        rmin, rcnt = int(rv[0]), int(rv[-1]) - int(rv[0]) + 1
+        first = np.searchsorted(rv, np.arange(rmin, rmin + rcnt), side="left")
+        last = np.searchsorted(rv, np.arange(rmin, rmin + rcnt), side="right")
+        dlo = (first - (S - 1)).astype(np.int16)
+        dcnt = (last - first).astype(np.int16)
+        _DRANGE[key] = (torch.from_numpy(dlo).to(dev), torch.from_numpy(dcnt).to(dev), int(dcnt.max()))
+    return _DRANGE[key]
 
 
 def gt_tilemasks(eng, run):
@@ -71,7 +95,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     # One launch prepares the backward: K^T, Q^T (head-major), PK^T, PQ^T and D_i = dO_i . O_i.  (Folding D into kernel A
     # was measured: +43 us there for the O tiles on its critical path; five separate small launches: 65 us in situ.)
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
-    if bufs is not None:
+    use_gt = bool(getattr(eng, "pos_grad_gt", False))  # rounds 1-5: G^T through HBM + split-K GEMMs
+    G1T = G2T = None
+    if bufs is not None and use_gt:
         G1T, G2T, QT, KT = bufs
     else:
         KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
@@ -94,21 +120,27 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     else:
         L.disent_attn_bwd_ds(q, k, v, dctx, pk, pq, relidx, run.mask_i32, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST,
                              B, S, Sp, nh, span2, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, lin=lin_a, row0=row0)
-    # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
-    if bufs is None:
-        G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
-        G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
-    if POISON_GT:  # test switch: blocks the shear kernel legitimately leaves unwritten must never be read
-        G1T.fill_(float("nan"))
-        G2T.fill_(float("nan"))
-    # (without klen the products read every row of G^T: everything outside the windows must then be zero-filled)
-    m1, m2 = gt_tilemasks(eng, run) if klen is not None else (None, None)
+    m1 = m2 = None
+    if use_gt:
+        # G^T is k-blocked: [nh][B][Sp/32][rcnt][32] (every shear workgroup writes one contiguous block)
+        if G1T is None:
+            G1T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+            G2T = torch.empty(nh, B * (Sp // 32) * rcnt * 32, dtype=BF16, device=dev)
+        if POISON_GT:  # test switch: blocks the shear kernel legitimately leaves unwritten must never be read
+            G1T.fill_(float("nan"))
+            G2T.fill_(float("nan"))
+        # (without klen the products read every row of G^T: everything outside the windows must then be zero-filled)
+        m1, m2 = gt_tilemasks(eng, run) if klen is not None else (None, None)
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
                             lin=lin, border=border, row0=row0, tilemask=m1)
     L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
                             rcnt=rcnt, lin=lin, border=border, row0=row0, tilemask=m2)
-    del dS, dST
-    state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen, masks=(m1, m2))
+    if use_gt:
+        del dS, dST
+        state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen, masks=(m1, m2))
+    else:
+        # fbl_attn_pos_grad reads dS / dS^T and the token rows of q / k themselves
+        state = dict(dS=dS, dST=dST, q=q, k=k, rmin=rmin, rcnt=rcnt, B=B, S=S, Sp=Sp, klen=klen, row0=row0)
     if defer_pos:
         return state
     dpos = pos_table_grads(eng, state, getattr(eng, "sk_ws", None))
@@ -121,8 +153,15 @@ def pos_table_grads(eng, st, ws):
     (head h owns columns h*64 .. h*64+63); per-head split-K GEMMs on the k-blocked G^T."""
     H, nh, span2 = eng.H, eng.nh, eng.span2
     rmin, rcnt, B, Sp = st["rmin"], st["rcnt"], st["B"], st["Sp"]
-    G1T, G2T, QT, KT = st["G1T"], st["G2T"], st["QT"], st["KT"]
     dpos = torch.zeros(span2, 2 * H, dtype=F32, device=eng.dev)
+    if "dS" in st:  # one execution through the fused kernel: [nh, rcnt, 64] per table -> the [dPQ | dPK] column blocks
+        dlo, dcnt, cmax = _delta_ranges(st["S"], eng.cfg, eng.dev)
+        for neg, X, Y, col0 in ((0, st["dS"], st["q"], H), (1, st["dST"], st["k"], 0)):
+            d = torch.empty(1, nh, rcnt, 64, dtype=F32, device=eng.dev)
+            L.attn_pos_grad(neg, [X], [Y], dlo, dcnt, cmax, d, B, st["S"], Sp, nh, rcnt, klen=st["klen"], row0=st["row0"])
+            dpos[rmin:rmin + rcnt, col0:col0 + H].view(rcnt, nh, 64).copy_(d[0].permute(1, 0, 2))
+        return dpos
+    G1T, G2T, QT, KT = st["G1T"], st["G2T"], st["QT"], st["KT"]
     Kc = B * Sp
     # split count: 5 at the bench shape (K = B*Sp = 10240).  Measured step time for 2 / 3 / 4 / 5 / 10 slices: 49.20 /
     # 48.90 / 48.89 / 48.56-48.71 / 48.88-48.95 ms (same box) -- half the partial-sum traffic of 10, still short workgroups
@@ -150,6 +189,10 @@ def pos_chain_buffers(eng, run, n_exec):
     rmin, rcnt = _relidx_range(S, eng.cfg)
     blk = B * (Sp // 32) * rcnt * 32
     dev = eng.dev
+    if not getattr(eng, "pos_grad_gt", False):
+        # the fused kernel reads every execution's dS / dS^T (2 x 157 MB at the bench shape, kept until the end of backward:
+        # the same 8 GB the G^T tensors took) and the token rows of its saved q / k
+        return dict(X1=[], X2=[], Yq=[], Yk=[], rmin=rmin, rcnt=rcnt, B=B, S=S, Sp=Sp, n=0, seeds=[], cap=n_exec, klen=None, row0=None)
     return dict(G1T=torch.empty(n_exec, nh, blk, dtype=BF16, device=dev), G2T=torch.empty(n_exec, nh, blk, dtype=BF16, device=dev),
                 QT=torch.empty(n_exec, nh, 64, B, Sp, dtype=BF16, device=dev), KT=torch.empty(n_exec, nh, 64, B, Sp, dtype=BF16, device=dev),
                 rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, n=0, seeds=[], cap=n_exec)
@@ -174,7 +217,15 @@ def pos_table_grads_batched(eng, run, pc):
     # [dPQ | dPK] of every execution, rows rmin .. rmin + rcnt of the tables (the others cannot be touched: their gradient is
     # zero): bf16 operand of the projection, fully written by the two copies below
     dpb = torch.empty(E, rcnt, 2 * H, dtype=BF16, device=dev)
-    masks = gt_tilemasks(eng, run) if ks else (None, None)
+    if "X1" in pc:
+        dlo, dcnt, cmax = _delta_ranges(pc["S"], eng.cfg, dev)
+        for neg, kx, ky, col0 in ((0, "X1", "Yq", H), (1, "X2", "Yk", 0)):
+            d = torch.empty(E, nh, rcnt, 64, dtype=F32, device=dev)
+            L.attn_pos_grad(neg, pc[kx][:E], pc[ky][:E], dlo, dcnt, cmax, d, B, pc["S"], Sp, nh, rcnt, klen=pc["klen"], row0=pc["row0"])
+            L.heads_to_rows_bf16(d, dpb[:, :, col0:col0 + H])
+        masks = ()
+    else:
+        masks = gt_tilemasks(eng, run) if ks else (None, None)
     for (key_g, key_t, col0), tmask in zip((("G1T", "QT", H), ("G2T", "KT", 0)), masks):
         G = pc[key_g][:E].view(E * nh, -1)
         a = torch.as_strided(G, (E * nh, rcnt, 32), (G.stride(0), 32, 1))

@@ -721,6 +721,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   const int row = r0 + rl;
   bf16* G = (bf16*)(smem + C_G);
   int16_t* idx = (int16_t*)(smem + C_IDX);
+  const bool wgt = a.GT != nullptr;  // G^T wanted (the per-head position-table GEMMs of rounds 1-5; fbl_attn_pos_grad reads dS itself)
   bf16* gt = a.GT + ((((long)h * a.B + b) * (Sp / 32) + bx) * a.rcnt) * 32;
   const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int kl = a.klen ? min(a.klen[b], S) : S;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   if (r0 >= kl) {  // rows entirely beyond the sample's last valid position: dS is zero -> zero output rows, zero G^T block
     // The consumer of G^T (the position-table GEMMs) skips a 64-wide k-step whose first row is beyond kl, so this block
     // only has to exist (as zeros) when it is the odd half of a step whose even half is valid.
-    if ((bx & 1) && (r0 - 32 < kl)) {
+    if (wgt && (bx & 1) && (r0 - 32 < kl)) {
       const uint32_t tm = a.tilemask ? a.tilemask[b * (Sp / 64) + (bx >> 1)] : ~0u;
       if (!(FBL_ATTN_DBGBITS & 64))
         for (int id = tid; id < a.rcnt * 4; id += 128)
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
   // G^T rows outside [rbase, rbase + nks*32) are zero: written straight from here -- only inside the 128-row tiles that the
   // consumer fetches for this 64-row k-step (tilemask: the tiles either of its two blocks can touch)
   const uint32_t tmask = a.tilemask ? a.tilemask[b * (Sp / 64) + (bx >> 1)] : ~0u;
-  for (int id = tid; id < a.rcnt * 4; id += 128) {
+  for (int id = tid; wgt && id < a.rcnt * 4; id += 128) {
     const int r = a.rmin + (id >> 2);
     if (!(FBL_ATTN_DBGBITS & 64) && ((tmask >> (id >> 9)) & 1) && (r < rbase || r >= rbase + nks * 32)) *(bf16x8*)(gt + (long)id * 8) = z8;
   }
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
     const bf16x8 bfv = *(const bf16x8*)(G + rl * LDG + kk * 32 + g * 8);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfv, acc[dt], 0, 0, 0);
+    if (!wgt) return;
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
     const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I0, zf, 0, 0, 0);  // [row g*4+j][table row kk*32 + c]
     const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv, I1, zf, 0, 0, 0);  // [row g*4+j][table row kk*32+16+c]
@@ -881,6 +883,200 @@ __global__ __launch_bounds__(128) void attn_bwd_shear_kernel(ShearArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
+  }
+}
+
+// ------------------------------------------------------------------------------------------- position-table gradients
+// dPK[h][r][d] = sum_b sum_{(i,j): idx(i-j) = r} dS_b[i,j] Q_b[i,d]        (NEG = 0: X = dS,   Y = Q, k index = query i)
+// dPQ[h][r][d] = sum_b sum_{(i,j): idx(i-j) = r} dS_b[i,j] K_b[j,d]        (NEG = 1: X = dS^T, Y = K, k index = key j)
+// of EVERY layer execution in one launch (autograd of model/deberta.py:870-918 through the c2p / p2c gathers), straight from
+// the dS / dS^T tensors kernel A wrote: until round 5 the shear passes wrote a sheared copy G^T of them (2 x 163 MB per layer
+// execution) that two batched split-K GEMMs fetched back at the end of backward (8 GB each way per step).  A table row r
+// collects the deltas [dlo[r], dlo[r] + dcnt[r]) (one inside the identity band, a few per log bucket; idx is monotone), so
+// with rows of X = dS (dS^T) staged in LDS the MFMA operand G[r][k] = sum_t X[k][k -+ (dlo[r] + t)] is a diagonal walk of
+// 16-bit reads -- 8 per fragment, against the 4 MFMAs it feeds.  One workgroup (4 waves) = one (execution, head, 256 table
+// rows): it walks all samples and their 32-row blocks, every wave keeps the [16 x 64] results of four 16-row tiles of table
+// rows in registers, and the sum over the batch never leaves them: no partial sums, no workspace, deterministic.  The two
+// workgroups of an (execution, head) sit on one XCD (they read the same rows of X).
+constexpr int PG_MAX_E = 64;  // layer executions per launch (the pointers travel as kernel arguments: capturable)
+struct PosGradArgs {
+  const bf16* X[PG_MAX_E];  // dS or dS^T of each execution: [B,nh,Sp,Sp]
+  const bf16* Y[PG_MAX_E];  // q or k: rows b*S + s (or packed: row0), head h at column h*64
+  long ldy;
+  const int16_t* dlo;     // [rcnt] first delta of table row rmin + r
+  const int16_t* dcnt;    // [rcnt] number of deltas of that row
+  const int32_t* klen;    // [B] or null
+  const int32_t* row0;    // [B+1] packed rows of Y or null
+  float* out;             // [E][nh][rcnt][64]
+  int E, B, S, Sp, nh, rcnt;
+  int cmax;               // max of dcnt (host)
+};
+constexpr int PG_PAD = 48;   // zero columns on both sides of the staged rows: a fragment of a tile that touches the valid range
+                             // reaches at most 15 + 31 columns beyond it
+constexpr int PG_LDY = 80;   // bf16 row stride of the Y tile (transposing reads, see LDP)
+constexpr int PG_TPW = 4;    // 16-row tiles of table rows per wave
+constexpr int PG_WAVES = 4, PG_THR = PG_WAVES * 64;
+constexpr int PG_ROWS = PG_WAVES * PG_TPW * 16;  // table rows per workgroup
+__host__ __device__ constexpr int pg_pitch(int Sp) { return Sp + 2 * PG_PAD; }          // bf16 elements
+__host__ __device__ constexpr int pg_buf(int Sp) { return 32 * pg_pitch(Sp) * 2 + 32 * PG_LDY * 2; }  // one staging buffer
+__host__ __device__ constexpr int pg_smem(int Sp) { return 2 * pg_buf(Sp); }
+
+// CM: upper bound of dcnt (deltas per table row): 3 covers S <= 300 at the DeBERTa-v2 bucket map, 8 every S <= 512
+// NXR: 16-byte chunks of X per thread and block (Sp / 64); OCC: workgroups per CU the register budget is set for (3: one staging
+// buffer and two barriers per item, 2: two buffers and one barrier)
+template <bool NEG, int CM, int NXR, int OCC>
+__global__ __launch_bounds__(PG_THR, OCC) void pos_grad_kernel(PosGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, Sp = a.Sp, P = pg_pitch(Sp);
+  // block -> (problem = execution * nh + head, part): the parts of a problem share its XCD (block L runs on XCD L % 8)
+  const int nsplit = (a.rcnt + PG_ROWS - 1) / PG_ROWS;
+  const int L8 = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int prob = (L8 / nsplit) * 8 + xcd, part = L8 % nsplit;
+  if (prob >= a.E * a.nh) return;
+  const int e = prob / a.nh, h = prob % a.nh;
+  const int bufsz = pg_buf(Sp);  // two staging buffers: [32][P] rows of X (column PG_PAD + j holds X[row][j]) + [32][PG_LDY] rows of Y
+  const bf16* X = a.X[e];
+  const bf16* Y = a.Y[e];
+  const int ntiles = (a.rcnt + 15) / 16;
+
+  // this wave's tiles: t = (w + 4 u) * nsplit + part (the parts and the waves take the tiles round-robin: the expensive
+  // log-bucket tiles at both ends of the table and the tiles a short sample touches are spread evenly).  Per tile: the lane's table row, its delta range, and the tile's (wave-uniform) delta span
+  int d0[PG_TPW], dn[PG_TPW], tlo[PG_TPW], thi[PG_TPW];
+  bool simple[PG_TPW];
+#pragma unroll
+  for (int u = 0; u < PG_TPW; ++u) {
+    const int t = (w + PG_WAVES * u) * nsplit + part;
+    const int r = min(t * 16 + c, a.rcnt - 1);
+    const bool live = t < ntiles && t * 16 + c < a.rcnt;
+    d0[u] = live ? (int)a.dlo[r] : 0;
+    dn[u] = live ? (int)a.dcnt[r] : 0;
+    const int rf = min(t * 16, a.rcnt - 1), rl = min(t * 16 + 15, a.rcnt - 1);
+    tlo[u] = t < ntiles ? (int)a.dlo[rf] : 1 << 20;
+    thi[u] = t < ntiles ? (int)a.dlo[rl] + (int)a.dcnt[rl] - 1 : -(1 << 20);
+    // identity band: one delta per row, consecutive rows <-> consecutive deltas (wave-uniform)
+    simple[u] = t < ntiles && t * 16 + 15 < a.rcnt && (thi[u] - tlo[u]) == 15 && __builtin_amdgcn_ballot_w64(dn[u] != 1) == 0;
+  }
+  f32x4 acc[PG_TPW][4];
+#pragma unroll
+  for (int u = 0; u < PG_TPW; ++u)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // the zero columns on both sides are written once (both buffers); the staging rewrites columns [0, Sp) of every row
+  for (int id = tid; id < (OCC >= 3 ? 1 : 2) * 32 * 2 * (PG_PAD / 8); id += PG_THR) {
+    const int bsel = id / (32 * 2 * (PG_PAD / 8)), r2 = id % (32 * 2 * (PG_PAD / 8));
+    const int row = r2 / (2 * (PG_PAD / 8)), q = r2 % (2 * (PG_PAD / 8));
+    const int col = q < PG_PAD / 8 ? q * 8 : PG_PAD + Sp + (q - PG_PAD / 8) * 8;
+    *(bf16x8*)((bf16*)(smem + bsel * bufsz) + row * P + col) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const bf16x8 z8 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  // staging role of this thread: row tid / 8 of the block, 16-byte chunks (tid % 8) + 8 q  (Sp is a multiple of 64: nq = Sp / 64
+  // chunks per thread; eight consecutive threads fetch 128 contiguous bytes) -- no integer division in the loop
+  const int srow = tid >> 3, sch = tid & 7, nq = Sp >> 6;
+
+  // work list: (sample b, 32-row block k0 < klen[b]) in order; the next item's operands are in flight (registers) during the
+  // current item's arithmetic
+  int b_n = 0, k_n = 0, kl_n = 0;
+  auto seek = [&]() {  // first item at or after (b_n, k_n)
+    while (b_n < a.B) {
+      kl_n = a.klen ? min(a.klen[b_n], S) : S;
+      if (k_n < kl_n) return true;
+      ++b_n; k_n = 0;
+    }
+    return false;
+  };
+  bf16x8 rx[NXR], ry;
+  int it_b = 0, it_k = 0, it_kl = 0;
+  auto load_item = [&]() {  // loads item (b_n, k_n) and advances the iterator
+    it_b = b_n; it_k = k_n; it_kl = kl_n;
+    const int kl64 = (kl_n + 63) & ~63;  // kernel A wrote the tile pairs below it; anything beyond is unwritten memory
+    const long rb = a.row0 ? (long)a.row0[b_n] : (long)b_n * S;
+    const int lim = a.row0 ? min(a.row0[b_n + 1] - a.row0[b_n], S) : S;
+    const bf16* Xb = X + (((long)b_n * a.nh + h) * Sp) * Sp + (long)k_n * Sp;
+    const bf16* xr = Xb + (long)srow * Sp + sch * 8;
+#pragma unroll
+    for (int q = 0; q < NXR; ++q) rx[q] = (q < nq && sch * 8 + q * 64 < kl64) ? *(const bf16x8*)(xr + q * 64) : z8;
+    {
+      const int pos = k_n + srow;
+      ry = (pos < lim) ? *(const bf16x8*)(Y + (rb + pos) * a.ldy + h * 64 + sch * 8) : z8;
+    }
+    k_n += 32;
+  };
+  int pb = 0;
+  bool have = seek();
+  if (have) load_item();
+  while (have) {
+    bf16* xs = (bf16*)(smem + pb * bufsz);
+    bf16* ys = xs + 32 * P;
+    if (OCC >= 3) __syncthreads();  // single buffer: the previous item's fragments are read
+    {
+      bf16* xw = xs + srow * P + PG_PAD + sch * 8;
+#pragma unroll
+      for (int q = 0; q < NXR; ++q)
+        if (q < nq) *(bf16x8*)(xw + q * 64) = rx[q];
+    }
+    *(bf16x8*)(ys + srow * PG_LDY + sch * 8) = ry;
+    const int k0 = it_k, kl = it_kl;
+    __syncthreads();  // one barrier per item: the buffer written two items from now was read one item ago, before this barrier
+    have = seek();
+    if (have) load_item();
+    // Y^T fragments (MFMA A operand: rows d = dt*16 + c, k = the 32 staged rows): transposing reads of the row-major tile
+    bf16x8 yf[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16* yb = ys + (g * 8 + (c >> 2)) * PG_LDY + dt * 16 + (c & 3) * 4;
+      union { tr16x4 hh[2]; bf16x8 v; } u2;
+      u2.hh[0] = lds_tr16(yb);
+      u2.hh[1] = lds_tr16(yb + 4 * PG_LDY);
+      yf[dt] = u2.v;
+    }
+#pragma unroll
+    for (int u = 0; u < PG_TPW; ++u) {
+      // columns this tile reads in this block: k -+ delta for k in [k0, k0+32), delta in [tlo, thi]; valid columns [0, kl)
+      const int cmin = NEG ? k0 + tlo[u] : k0 - thi[u];
+      const int cmax = NEG ? k0 + 31 + thi[u] : k0 + 31 - tlo[u];
+      if (cmax < 0 || cmin >= kl) continue;  // (wave-uniform)
+      bf16x8 gf;
+      // G[r][k] = sum_t X[k][k -+ (d0 + t)]: lane (table row c, k chunk g) walks diagonals of the staged rows
+      const bf16* xrow = xs + (g * 8) * P + PG_PAD;
+      const int cb = NEG ? (k0 + g * 8 + d0[u]) : (k0 + g * 8 - d0[u]);  // column of row g*8 (q = 0, t = 0)
+      if (simple[u]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gf[q] = xrow[q * P + cb + q];
+      } else {
+        // log buckets (a few deltas per row, <= a.cmax) and edge tiles: columns are clamped into the zero margins
+        // (all 8 x CM reads are issued before the first one is used: a read-use-read chain costs an LDS latency per element)
+        const int lo = -PG_PAD, hi = Sp + PG_PAD - 1;
+        bf16 vv[8][CM];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int t2 = 0; t2 < CM; ++t2) vv[q][t2] = xrow[q * P + clampi(NEG ? cb + q + t2 : cb + q - t2, lo, hi)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float sum = 0.f;
+#pragma unroll
+          for (int t2 = 0; t2 < CM; ++t2) sum += t2 < dn[u] ? bf2f(vv[q][t2]) : 0.f;
+          gf[q] = f2bf(sum);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[dt], gf, acc[u][dt], 0, 0, 0);
+    }
+    if (OCC < 3) pb ^= 1;
+  }
+  // lane: table row t*16 + c, columns d = dt*16 + g*4 .. +3
+  float* ob = a.out + ((long)e * a.nh + h) * a.rcnt * 64;
+#pragma unroll
+  for (int u = 0; u < PG_TPW; ++u) {
+    const int r = ((w + PG_WAVES * u) * nsplit + part) * 16 + c;
+    if (r < a.rcnt) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *(f32x4*)(ob + (long)r * 64 + dt * 16 + g * 4) = acc[u][dt];
+    }
   }
 }
 
@@ -977,7 +1173,7 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   if (B <= 0 || nh <= 0) return 0;
   // index range reachable from 32 consecutive rows: <= S + 31 entries (idx has slope <= 1), +7 for the 8-alignment
   const int Wg = shear_wg(S, span2);
-  if (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2) return FBL_ERR_ARG;
+  if (GT && (gt_rmin < 0 || gt_rcnt < 0 || gt_rmin + gt_rcnt > span2)) return FBL_ERR_ARG;
   if (row0 && !klen) return FBL_ERR_ARG;
   ShearArgs a{(const bf16*)X, (const bf16*)YT, y_sh, y_sb, y_sd, (const bf16*)PT, relidx, klen, border, (bf16*)out, ldout, (bf16*)GT,
               B, S, Sp, nh, span2, Wg, gt_rmin, gt_rcnt, lin_span, row0, gt_tilemask};
@@ -1005,6 +1201,61 @@ extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT,
   else
     hipLaunchKernelGGL(attn_bwd_shear_kernel<false>, grid, dim3(128), smem_bytes, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_attn_pos_grad(int neg, const void* const* X, const void* const* Y, int64_t ldy, const int16_t* dlo,
+                                 const int16_t* dcnt, int dcnt_max, const int32_t* klen, const int32_t* row0, float* out, int E,
+                                 int B, int S, int Sp, int nh, int rcnt, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64 || rcnt < 1 || rcnt > 1024) return FBL_ERR_SHAPE;
+  if (ldy % 8) return FBL_ERR_ALIGN;
+  if (!X || !Y || !dlo || !dcnt || !out || dcnt_max < 1 || dcnt_max > 8) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
+  if (E <= 0 || B <= 0 || nh <= 0) return 0;
+  for (int e = 0; e < E; ++e)
+    if (!X[e] || !Y[e]) return FBL_ERR_ARG;
+  // three workgroups per CU (one staging buffer) where the rows are short enough for five chunks per thread, two otherwise
+  static const int occ_sw = FBL_ENV_INT("FBL_POSGRAD_OCC", 3);
+  const bool occ3 = Sp <= 320 && dcnt_max <= 3 && occ_sw >= 3;
+  const int smem_bytes = occ3 ? pg_buf(Sp) : pg_smem(Sp);
+  static int attr_bytes = 0;
+  if (pg_smem(Sp) > attr_bytes) {
+    const void* fns[6] = {(const void*)pos_grad_kernel<false, 3, 5, 3>, (const void*)pos_grad_kernel<true, 3, 5, 3>,
+                          (const void*)pos_grad_kernel<false, 3, 8, 2>, (const void*)pos_grad_kernel<true, 3, 8, 2>,
+                          (const void*)pos_grad_kernel<false, 8, 8, 2>, (const void*)pos_grad_kernel<true, 8, 8, 2>};
+    for (int i = 0; i < 6; ++i) {
+      hipError_t e1 = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, pg_smem(Sp));
+      if (e1 != hipSuccess) return (int)e1;
+    }
+    attr_bytes = pg_smem(Sp);
+  }
+  const int nsplit = (rcnt + PG_ROWS - 1) / PG_ROWS;
+  for (int e0 = 0; e0 < E; e0 += PG_MAX_E) {
+    PosGradArgs a{};
+    const int ne = E - e0 < PG_MAX_E ? E - e0 : PG_MAX_E;
+    for (int e = 0; e < ne; ++e) {
+      a.X[e] = (const bf16*)X[e0 + e];
+      a.Y[e] = (const bf16*)Y[e0 + e];
+    }
+    a.ldy = ldy; a.dlo = dlo; a.dcnt = dcnt; a.klen = klen; a.row0 = row0;
+    a.out = out + (long)e0 * nh * rcnt * 64;
+    a.E = ne; a.B = B; a.S = S; a.Sp = Sp; a.nh = nh; a.rcnt = rcnt; a.cmax = dcnt_max;
+    const dim3 grid((unsigned)(((ne * nh + 7) / 8) * 8 * nsplit));
+#define FBL_PG_LAUNCH(NEG_, CM_, NXR_, OCC_) \
+  hipLaunchKernelGGL((pos_grad_kernel<NEG_, CM_, NXR_, OCC_>), grid, dim3(PG_THR), smem_bytes, (hipStream_t)stream, a)
+    if (occ3) {
+      if (neg) FBL_PG_LAUNCH(true, 3, 5, 3);
+      else FBL_PG_LAUNCH(false, 3, 5, 3);
+    } else if (dcnt_max <= 3) {
+      if (neg) FBL_PG_LAUNCH(true, 3, 8, 2);
+      else FBL_PG_LAUNCH(false, 3, 8, 2);
+    } else {
+      if (neg) FBL_PG_LAUNCH(true, 8, 8, 2);
+      else FBL_PG_LAUNCH(false, 8, 8, 2);
+    }
+#undef FBL_PG_LAUNCH
+    FBL_CHECK_LAUNCH();
+  }
   return 0;
 }
 

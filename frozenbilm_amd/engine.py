@@ -133,6 +133,8 @@ class Engine:
         #   attn_save_p    False = the attention backward recomputes the probabilities (rounds 1-5) instead of reading the ones the
         #                  training forward saved (157 MB per layer execution at the bench shape, held until the backward)
         self.attn_save_p = bool(o.get("attn_save_p", True))
+        #   pos_grad_gt    True = position-table gradients through G^T and split-K GEMMs (rounds 1-5) instead of fbl_attn_pos_grad
+        self.pos_grad_gt = bool(o.get("pos_grad_gt", False))
         self.fuse_tail = bool(o.get("fuse_tail", True))
         L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(o.get("dw_group", 16))))  # adapter gradient products per launch (<= 16)
@@ -1167,10 +1169,14 @@ class Engine:
         bufs = None
         if pc is not None:
             e = pc["n"]
-            bufs = (pc["G1T"][e], pc["G2T"][e], pc["QT"][e], pc["KT"][e])
+            if "G1T" in pc:
+                bufs = (pc["G1T"][e], pc["G2T"][e], pc["QT"][e], pc["KT"][e])
             pc["seeds"].append(sv.seed_pos)
             pc["n"] = e + 1
-        disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True, bufs=bufs)
+        st = disent_attn_bwd(self, run, sv, dctx, dqkv, None, defer_pos=True, bufs=bufs)
+        if pc is not None and "X1" in pc:  # the fused position-gradient kernel reads these at the end of backward
+            pc["X1"].append(st["dS"]); pc["X2"].append(st["dST"]); pc["Yq"].append(st["q"]); pc["Yk"].append(st["k"])
+            pc["klen"], pc["row0"] = st["klen"], st["row0"]
         return dqkv
 
     def _head_bwd(self, run, rows, dlog, dq, all_rows=False):

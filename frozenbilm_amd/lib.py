@@ -61,6 +61,7 @@ SIGNATURES = {
                                      _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_shear": (_i, [_i, _vp, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _vp, _vp, _vp]),
+    "fbl_attn_pos_grad": (_i, [_i, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fbl_gt_tilemask": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_ce_fwd": (_i, [_vp, _l, _vp, _i, _i, _vp, _vp, _vp]),
     "fbl_ce_bwd_rows": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -579,6 +580,23 @@ def disent_attn_bwd_dsp(psave, msave, v, dO, lse, Dv, scale, dV, dS, dST, B, S, 
     _chk(load().fbl_disent_attn_bwd_dsp(_p(psave), _p(msave), _p(v), ldv, _p(dO), ldo, _p(klen), _p(border), _p(lse), _p(Dv),
                                         float(scale), float(p_drop), int(seed), _seed_dev(), _p(dV), lddv, _p(dS), _p(dST),
                                         B, S, Sp, nh, _row0(row0, B, klen), _stream()), "fbl_disent_attn_bwd_dsp")
+
+
+def attn_pos_grad(neg, Xs, Ys, dlo, dcnt, dcnt_max, out, B, S, Sp, nh, rcnt, klen=None, row0=None):
+    """out[e, h, r, :] fp32 = position-table gradient (neg=0: dPK from dS and q; neg=1: dPQ from dS^T and k) of the layer
+    executions whose tensors are listed in Xs / Ys (include/fbl.h fbl_attn_pos_grad)"""
+    E = len(Xs)
+    assert E == len(Ys) and E > 0
+    ldy = _rows2d(Ys[0], "Y")
+    for x, y in zip(Xs, Ys):
+        _req(x, torch.bfloat16, "X"); _req(y, torch.bfloat16, "Y")
+        assert x.is_contiguous() and x.numel() == B * nh * Sp * Sp and _rows2d(y, "Y") == ldy
+    _req(dlo, torch.int16, "dlo"); _req(dcnt, torch.int16, "dcnt"); _req(out, torch.float32, "out")
+    assert dlo.numel() == rcnt and dcnt.numel() == rcnt and out.is_contiguous() and out.numel() == E * nh * rcnt * 64
+    xp = (C.c_void_p * E)(*[x.data_ptr() for x in Xs])
+    yp = (C.c_void_p * E)(*[y.data_ptr() for y in Ys])
+    _chk(load().fbl_attn_pos_grad(int(neg), xp, yp, ldy, _p(dlo), _p(dcnt), int(dcnt_max), _p(klen), _row0(row0, B, klen), _p(out),
+                                  E, B, S, Sp, nh, int(rcnt), _stream()), "fbl_attn_pos_grad")
 
 
 def gt_tilemask(relidx, klen, B, S, Sp, span2, neg, rmin, rcnt):

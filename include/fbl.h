@@ -287,6 +287,18 @@ int fbl_disent_attn_probs(const void* q, const void* k, int64_t ldq, const void*
  * With klen given, G^T blocks (32 rows) of 64-row steps that start beyond klen[b] are left UNWRITTEN: their consumer
  * (fbl_gemm_bf16_nt with kskip_len = klen) never reads them. */
 int fbl_attn_rowdot(const void* dO, const void* O, int64_t ld, float* out, int B, int S, int nh, void* stream);
+/* Position-table gradients of E layer executions in one launch, straight from the dS / dS^T tensors of fbl_disent_attn_bwd_ds(p):
+ *   neg = 0: out[e][h][r][d] = dPK = sum_b sum_{(i,j): relidx(i-j) = rmin + r} dS[i,j] * Q[b*S+i, h*64+d]     (X = dS,   Y = q)
+ *   neg = 1: out[e][h][r][d] = dPQ = sum_b sum_{(i,j): relidx(i-j) = rmin + r} dS[i,j] * K[b*S+j, h*64+d]     (X = dS^T, Y = k)
+ * X, Y: HOST arrays of E device pointers (X[e]: bf16 [B,nh,Sp,Sp]; Y[e]: bf16 rows of stride ldy, packed by row0 if given);
+ * dlo / dcnt int16 [rcnt] (device): table row rmin + r collects the deltas i-j in [dlo[r], dlo[r] + dcnt[r]) (relidx is
+ * monotone: the inverse of the index vector), dcnt_max = max(dcnt) (host value); klen as in fbl_disent_attn_bwd_ds (only the written corner of X is read);
+ * out fp32 [E, nh, rcnt, 64], fully written (no accumulation, no workspace, bit-reproducible).  When this entry point is used
+ * fbl_disent_attn_bwd_shear may be called with GT = NULL (no G^T is written).
+ * ref: autograd of model/deberta.py:870-918 (c2p / p2c gathers) and :847-853 (the position projections' inputs). */
+int fbl_attn_pos_grad(int neg, const void* const* X, const void* const* Y, int64_t ldy, const int16_t* dlo, const int16_t* dcnt,
+                      int dcnt_max, const int32_t* klen, const int32_t* row0, float* out, int E, int B, int S, int Sp, int nh,
+                      int rcnt, void* stream);
 /* mask[b*(Sp/64) + j] (uint32): which 128-row tiles of the gt_rcnt rows of G^T (row 0 = table row gt_rmin) the 64-row k-step j of
  * sample b can touch (neg as in fbl_disent_attn_bwd_shear; klen optional).  A function of the lengths and the relative-index map only:
  * computed once per backward pass and handed to every shear launch (gt_tilemask: rows outside the marked tiles are not written)

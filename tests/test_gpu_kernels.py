@@ -706,7 +706,7 @@ def test_attention_fwd_dropout_rate(L):
     assert ctx.float().std().item() > 1e-3  # not all ones: dropout really dropped something
 
 
-@pytest.mark.parametrize("saved_p", [False, True], ids=["recompute", "saved_p"])
+@pytest.mark.parametrize("saved_p", [False, True, "gt_route"], ids=["recompute", "saved_p", "gt_route"])
 @pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1), (4, 200, 2)])
 def test_attention_bwd(L, B, S, nh, saved_p):
     """saved_p: kernel A reads the un-normalised probabilities the (training) forward left in HBM (fbl_disent_attn_bwd_dsp)
@@ -723,6 +723,8 @@ def test_attention_bwd(L, B, S, nh, saved_p):
     qkv = (qkv.float() * 0.5).to(BF16)
     pqk = (pqk.float() * 0.5).to(BF16)
     klen_t = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
+    gt_route = saved_p == "gt_route"  # position-table gradients through G^T + split-K GEMMs (rounds 1-5) instead of fbl_attn_pos_grad
+    saved_p = saved_p is True
     saved = [] if saved_p else None
     ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, klen=klen_t, save_p=saved)
     dctx = bf(rnd(B * S, H, seed=5)).to(BF16)
@@ -744,6 +746,7 @@ def test_attention_bwd(L, B, S, nh, saved_p):
     import types as _t
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
+    eng.pos_grad_gt = gt_route
     run.klen = klen_t
     run.border = _border(run.klen) if (run.klen is not None and B >= 3) else None  # longest-first dispatch (XCD-aware map at B=4)
     import frozenbilm_amd.attn_bwd as AB

@@ -82,6 +82,32 @@ def bwd_p():  # kernel A from the saved probabilities
                           klen=klen, border=border)
 
 
+from frozenbilm_amd.attn_bwd import _delta_ranges  # noqa: E402
+import types  # noqa: E402
+
+dlo, dcnt, dcmax = _delta_ranges(S, types.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256), torch.device(dev))
+EPG = int(os.environ.get("EPG", "1"))  # executions per fbl_attn_pos_grad launch (25 = the end-of-backward launch, cold operands)
+dpos = torch.empty(EPG, nh, rcnt, 64, device=dev)
+_xs1 = [dS] + [torch.empty_like(dS).copy_(dS) for _ in range(EPG - 1)]
+_xs2 = [dST] + [torch.empty_like(dST).copy_(dST) for _ in range(EPG - 1)]
+_ys = [qkv] + [qkv.clone() for _ in range(EPG - 1)]
+
+
+def posgrad():
+    L.attn_pos_grad(0, _xs1, [y[:, :H] for y in _ys], dlo, dcnt, dcmax, dpos, B, S, Sp, nh, rcnt, klen=klen)
+    L.attn_pos_grad(1, _xs2, [y[:, H:2 * H] for y in _ys], dlo, dcnt, dcmax, dpos, B, S, Sp, nh, rcnt, klen=klen)
+
+
+def shear0n():
+    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], None, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
+                            lin=128, border=border)
+
+
+def shear1n():
+    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], None, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
+                            rcnt=rcnt, lin=128, border=border)
+
+
 def prep():
     if os.environ.get("PREP_SPLIT") == "1":  # the five separate launches the fused preparation replaced
         L.attn_rowdot(dctx, ctx, Dv, B, S, nh)
@@ -137,8 +163,10 @@ def shear_both():  # the two shear passes are independent: second one on a side 
 
 fwd_save()
 prep()
+bwd_p()
 res = {n: timeit(f) for n, f in (("fwd", fwd), ("fwd_save", fwd_save), ("prep", prep), ("bwd_a", bwd_a), ("bwd_p", bwd_p),
-                                 ("shear0", shear0), ("shear1", shear1), ("shear0||1", shear_both))}
+                                 ("shear0", shear0), ("shear1", shear1), ("shear0_nogt", shear0n), ("shear1_nogt", shear1n),
+                                 (f"posgrad_x{EPG}", posgrad), ("shear0||1", shear_both))}
 npairs = int(sum(((int(k) + 63) // 64) ** 2 for k in klen.tolist()) * nh)
 tag = f"pairs={npairs} order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
 print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total (recompute) {res['prep'] + res['bwd_a'] + res['shear0'] + res['shear1']:.1f}us, (saved P) "
