@@ -96,15 +96,23 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     # was measured: +43 us there for the O tiles on its critical path; five separate small launches: 65 us in situ.)
     Dv = torch.empty(B, nh, S, dtype=F32, device=dev)
     use_gt = bool(getattr(eng, "pos_grad_gt", False))  # rounds 1-5: G^T through HBM + split-K GEMMs
+    # round 6: with the forward's probabilities saved, kernel A forms dK itself (fbl_disent_attn_bwd_dspk) -- no key-major shear
+    # pass, no Q^T / PQ^T copies; engine_options["attn_fused_dk"] = False keeps the separate pass
+    fused_dk = getattr(sv, "psave", None) is not None and not use_gt and bool(getattr(eng, "attn_fused_dk", True))
     G1T = G2T = None
+    QT = PQT = PQX = None
     if bufs is not None and use_gt:
         G1T, G2T, QT, KT = bufs
     else:
         KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
-        QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+        if not fused_dk:
+            QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
-    PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
-    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0)
+    if fused_dk:
+        PQX = torch.empty(nh, 64, 2 * Sp, dtype=BF16, device=dev)
+    else:
+        PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
+    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0, relidx=relidx, PQX=PQX)
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
@@ -112,7 +120,11 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     # |i-j| < lin: identity buckets, relidx injective (model/deberta.py:578-589: mid = bucket_size // 2)
     lin = eng.cfg.position_buckets // 2 if eng.cfg.position_buckets > 0 else 1 << 30
     lin_a = min(lin, span2 // 2) if eng.cfg.position_buckets > 0 else 0  # affine addressing of kernel A: identity buckets only
-    if getattr(sv, "psave", None) is not None:
+    if fused_dk:
+        L.disent_attn_bwd_dspk(sv.psave, sv.msave, q, v, dctx, PQX, sv.lse, Dv, scale, dqkv[:, H:2 * H], dqkv[:, 2 * H:], dS, dST,
+                               B, S, Sp, nh, p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, row0=row0)
+        sv.psave = sv.msave = None
+    elif getattr(sv, "psave", None) is not None:
         # the training forward saved its probabilities: no recomputation of the scores (fbl_disent_attn_bwd_dsp)
         L.disent_attn_bwd_dsp(sv.psave, sv.msave, v, dctx, sv.lse, Dv, scale, dqkv[:, 2 * H:], dS, dST, B, S, Sp, nh,
                               p_drop=run.p_att, seed=sv.seed_att, klen=klen, border=border, row0=row0)
@@ -133,8 +145,9 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
         m1, m2 = gt_tilemasks(eng, run) if klen is not None else (None, None)
     L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
                             lin=lin, border=border, row0=row0, tilemask=m1)
-    L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
-                            rcnt=rcnt, lin=lin, border=border, row0=row0, tilemask=m2)
+    if not fused_dk:
+        L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
+                                rcnt=rcnt, lin=lin, border=border, row0=row0, tilemask=m2)
     if use_gt:
         del dS, dST
         state = dict(G1T=G1T, G2T=G2T, QT=QT, KT=KT, rmin=rmin, rcnt=rcnt, B=B, Sp=Sp, klen=klen, masks=(m1, m2))

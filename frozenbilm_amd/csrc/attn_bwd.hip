@@ -60,22 +60,31 @@ struct PrepArgs {
   const bf16* dO; const bf16* O; long ldo;
   bf16* QT; bf16* KT; bf16* PQT; bf16* PKT; float* Dv;
   int B, S, Sp, nh, span2;
-  int n_tr, n_tab;  // blocks of one K / Q transpose, of one table transpose
+  int n_kt, n_qt, n_pkt, n_pqt;  // blocks of the K / Q transposes and of the PK / PQ table transposes (0: output not wanted)
   const int32_t* row0;  // [B+1] packed-row layout of q / k / dO / O (see attn_fwd.hip) or null; the outputs keep [B, S(p)]
+  // tables expanded by the relative-index map (the fused key-/query-major passes): X[h][d][t] = tab[relidx[t - Sp + S - 1]][h*64 + d],
+  // t in [0, 2 Sp) standing for delta = i - j = t - Sp (indices beyond the map's range are clamped: dS is zero there)
+  const int16_t* relidx;
+  bf16* PQX; bf16* PKX;
+  int n_pqx, n_pkx;
 };
 
 // vt[h*sh + b*sb + d*sd + s] = v[rb+s, h*64+d] (s < S), 0 for S <= s < Sp: one (64-position tile, head, sample); rb = first
 // row of the sample (b*S in the padded layout), S = number of its rows that exist
+// rowmap (optional): position s reads source row rowmap[clamp(s + map_off, 0, map_hi)] instead of rb + s
 __device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* v, long ldv, bf16* vt, int S, int Sp, long sh,
-                                                    long sb, long sd, int s0, int h, int b, long rb) {
+                                                    long sb, long sd, int s0, int h, int b, long rb,
+                                                    const int16_t* rowmap = nullptr, int map_off = 0, int map_hi = 0, int src_rows = 0) {
   const int t = threadIdx.x;
   {
     const int row = t >> 2, c0 = (t & 3) * 2;
     const int s = s0 + row;
+    long srow = rb + s;
+    if (rowmap) srow = min((int)rowmap[min(max(s + map_off, 0), map_hi)], src_rows - 1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (s < S) x = *(const uint4*)(v + (rb + s) * ldv + h * 64 + (c0 + c) * 8);
+      if (s < S) x = *(const uint4*)(v + srow * ldv + h * 64 + (c0 + c) * 8);
       uint32_t* d = tile + row * 33 + (c0 + c) * 4;
       d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
     }
@@ -100,9 +109,9 @@ __device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* 
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
   __shared__ uint32_t tile[64 * 33];
   int id = blockIdx.x;
-  if (id < 2 * a.n_tr) {  // K^T (first n_tr blocks) and Q^T, head-major
-    const bool isq = id >= a.n_tr;
-    if (isq) id -= a.n_tr;
+  if (id < a.n_kt + a.n_qt) {  // K^T (first n_kt blocks) and Q^T, head-major
+    const bool isq = id >= a.n_kt;
+    if (isq) id -= a.n_kt;
     const int nst = a.Sp / 64;
     const int st = id % nst, h = (id / nst) % a.nh, b = id / (nst * a.nh);
     const long rb = a.row0 ? (long)a.row0[b] : (long)b * a.S;
@@ -111,17 +120,27 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
                         st * 64, h, b, rb);
     return;
   }
-  id -= 2 * a.n_tr;
-  if (id < 2 * a.n_tab) {  // PK^T, PQ^T: [nh][64][span2]
-    const bool isq = id >= a.n_tab;
-    if (isq) id -= a.n_tab;
+  id -= a.n_kt + a.n_qt;
+  if (id < a.n_pkt + a.n_pqt) {  // PK^T, PQ^T: [nh][64][span2]
+    const bool isq = id >= a.n_pkt;
+    if (isq) id -= a.n_pkt;
     const int nst = a.span2 / 64;
     const int st = id % nst, h = id / nst;
     head_transpose_tile(tile, isq ? a.pq : a.pk, a.ldp, isq ? a.PQT : a.PKT, a.span2, a.span2, 64l * a.span2,
                         (long)a.nh * 64 * a.span2, a.span2, st * 64, h, 0, 0);
     return;
   }
-  id -= 2 * a.n_tab;
+  id -= a.n_pkt + a.n_pqt;
+  if (id < a.n_pqx + a.n_pkx) {  // expanded tables [nh][64][2 Sp]
+    const bool isk = id >= a.n_pqx;
+    if (isk) id -= a.n_pqx;
+    const int W = 2 * a.Sp, nst = W / 64;
+    const int st = id % nst, h = id / nst;
+    head_transpose_tile(tile, isk ? a.pk : a.pq, a.ldp, isk ? a.PKX : a.PQX, W, W, 64l * W, (long)a.nh * 64 * W, W, st * 64, h, 0, 0,
+                        a.relidx, a.S - 1 - a.Sp, 2 * a.S - 2, a.span2);
+    return;
+  }
+  id -= a.n_pqx + a.n_pkx;
   {  // D[b,h,s] = dO_row . O_row over the head's 64 columns: 8 lanes per (row, head)
     const long gid = (long)id * 256 + threadIdx.x;
     const long idx = gid >> 3;
@@ -649,6 +668,267 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dsp_kernel(BwdPArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- kernel A + the key-major shear pass
+// attn_bwd_dsp with dK formed in place (round 6): the workgroup of a 64-key tile already holds every dS[i, j] of its keys, one
+// query tile at a time, so both terms of
+//     dK_j = sum_i dS[i,j] Q_i  +  sum_i dS[i,j] PQ[idx(i-j)]
+// are accumulated next to dV instead of by a second kernel that reads dS^T back (attn_bwd_shear<NEG = 1>: 78 us and 157 MB per
+// layer execution at the bench shape):
+//  * dK^T += Q^T . dS: the dS values are MFMA B operands exactly as they sit in the accumulator layout (like drop(P) for dV), the
+//    Q^T fragments are transposing reads of a row-major Q tile staged beside the dO tile;
+//  * the position term is a Toeplitz product, dK_j += sum_delta dS[j+delta, j] PQX[delta], with PQX the table expanded by the
+//    relative-index map (fbl_attn_bwd_prep: PQX[h][d][delta + Sp] = PQ[idx(delta)], so log buckets and the identity band are
+//    one case and the kernel holds no index table).  Each wave writes its 16 keys' dS values a second time into a SHEARED tile
+//    G2[j][x], x = (i - i0) - (j - j0) + 64 (16-bit stores; the zero entries of the parallelogram are written once, before the
+//    loop) and reads aligned 16-byte MFMA B fragments back from its own rows -- no barrier; the A fragments PQX^T[d][delta..+7]
+//    are 16-byte loads of the L2-resident table (2 Sp x 64 per head).  A wave's keys reach 96 of the 128 deltas of a pair:
+//    3 k-steps x 4 MFMAs.
+// dS / dS^T are still written (fbl_attn_pos_grad and the query-major pass read them).
+struct BwdPKArgs {
+  BwdPArgs p;
+  const bf16* q; long ldq;   // row-major like v, head h at column h*64
+  const bf16* pqx;           // [nh][64][2 Sp]
+  bf16* dK; long lddk;
+};
+constexpr int LDG2 = 136;                    // bf16 row stride of the sheared tile (128 used)
+constexpr int K_DOS = 0;                     // [64 i][64] bf16 swizzled
+constexpr int K_QS = K_DOS + 8192;           // [64 i][64] bf16 swizzled
+constexpr int K_PS = K_QS + 8192;            // [64 i][LDP] bf16: P~, then (same columns per wave) the dS staging tile
+constexpr int K_STT = K_PS + 64 * LDP * 2;   // dS^T staging [64 j][LDV]
+constexpr int K_G2 = K_STT + 64 * LDV * 2;   // sheared dS^T [64 j][LDG2]
+constexpr int K_ROW = K_G2 + 64 * LDG2 * 2;  // float f[64], D[64]
+constexpr int K_TOTAL = K_ROW + 512;
+static_assert(3 * K_TOTAL <= 160 * 1024, "three workgroups per CU");
+
+struct PKTileRegs {
+  bf16x8 d[2], p[2], q[2];
+  float m, l, D;  // raw: msave, lse, D of query row tid (f = exp2(m - l*log2 e) is formed when the tile is stored: a use right behind
+                  // the loads would park wave 0 -- and with it the workgroup's next barrier -- for a full memory latency per pair)
+};
+
+template <bool PACKED = false>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BwdPArgs& a = ka.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, Sp = a.Sp;
+  const WgCoord wc = wg_coord(Sp / 64, a.nh, a.B, a.border);
+  const int j0 = wc.x * 64, h = wc.h, b = wc.b;
+  const int j = j0 + w * 16 + c;  // this lane's key
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;
+  const int jc = min(j, lim - 1);
+  float* rF = (float*)(smem + K_ROW);
+  float* rD = rF + 64;
+  bf16* dst = (bf16*)(smem + K_PS);     // dS tile [query][key], row stride LDP (aliases the P~ tile: a wave reads and writes
+                                        // only the 16 key columns it owns)
+  bf16* dstT = (bf16*)(smem + K_STT);   // dS^T tile [key][query]
+  bf16* g2 = (bf16*)(smem + K_G2) + (w * 16 + c) * LDG2;  // this lane's row of the sheared tile
+
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nqt = (j0 < kl) ? (kl + 63) / 64 : 0;
+  const int srow = tid >> 3, sch = tid & 7;
+  const int fb0 = c * 128 + ((g ^ (c & 7)) << 4), fb1 = fb0 ^ 64;  // dO fragment of row x*16 + c: + x*2048
+  const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);           // dO / Q staging slot of row srow + 32 t: + t*4096
+  const int sp = srow * (LDP * 2) + sch * 16;                      // P staging slot: + t*32*LDP*2
+
+  bf16x8 vf[2];
+  {
+    const long off = (rb + jc) * a.ldv + h * 64 + g * 8;
+    vf[0] = *(const bf16x8*)(a.v + off);
+    vf[1] = *(const bf16x8*)(a.v + off + 32);
+  }
+  f32x4 dv[4], dk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const DropKey dkey = attn_drop_key(a.p_drop > 0.f ? fbl_seed(a.seed, a.seed_dev) : 0, b * a.nh + h, a.p_drop);
+  const long sbase = ((long)b * a.nh + h) * Sp * Sp;
+  const float* mrow = a.msave + (((long)b * a.nh + h) * (Sp >> 6) + wc.x) * S;
+  // the sheared tile starts as zeros; the loop only ever rewrites the entries inside the parallelogram
+  if (nqt > 0)
+    for (int t = tid; t < (64 * LDG2 * 2) / 16; t += 256) *(bf16x8*)(smem + K_G2 + t * 16) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  // PQX^T fragments: row d = dt*16 + c, deltas t0 + ks*32 + g*8 .. +7 (t0 = i0 - j0 - 64 + Sp, a multiple of 64)
+  const int W2 = 2 * Sp;
+  const int ks0 = (w < 2) ? 1 : 0;  // this wave's keys reach x in [49 - 16 w, 128 - 16 w): three of the four 32-wide k-steps
+  // Global addresses as a wave-uniform base (buffer descriptor in scalar registers, advanced per pair by a scalar offset) + a
+  // 32-bit lane offset that does not change over the loop: 64-bit per-lane pointers for the seven streams of this kernel cost
+  // 24 spilled registers
+  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(ka.pqx + (long)h * 64 * W2 + (Sp - j0 - 64) + ks0 * 32);
+  const uint32_t xo = (uint32_t)((c * W2 + g * 8) * 2);
+  const __amdgpu_buffer_rsrc_t dOr = buf_rsrc(a.dO + rb * a.ldo + h * 64);
+  const __amdgpu_buffer_rsrc_t qr = buf_rsrc(ka.q + rb * ka.ldq + h * 64);
+  const __amdgpu_buffer_rsrc_t pr = buf_rsrc(a.psave + sbase + j0);
+  const __amdgpu_buffer_rsrc_t dSr = buf_rsrc(a.dS + sbase + j0);
+  const __amdgpu_buffer_rsrc_t dSTr = buf_rsrc(a.dST + sbase + (long)j0 * Sp);
+  const uint32_t ldo2 = (uint32_t)(a.ldo * 2), ldq2 = (uint32_t)(ka.ldq * 2);
+  const uint32_t po = (uint32_t)((srow * Sp + sch * 8) * 2);  // element (srow, sch*8) of a [64 x 64] block of an [Sp x Sp] matrix: + t*32*Sp*2
+  auto load_tile = [&](int it, PKTileRegs& R) {
+    const int i0 = it * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t ir = (uint32_t)min(i0 + srow + t * 32, lim - 1);
+      R.d[t] = buf_ld16(dOr, ir * ldo2 + (uint32_t)(sch * 16), 0);
+      R.p[t] = buf_ld16(pr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * Sp * 2));
+    }
+    {  // (every wave loads, clamped: no branch, no wait; only wave 0's values are stored)
+      const int i = min(i0 + lane, lim - 1);
+      const long o = ((long)b * a.nh + h) * S + i;
+      R.l = a.lse[o];
+      R.m = mrow[i];
+      R.D = a.Dv[o];
+    }
+  };
+  // (the Q rows of the next pair are requested later in the pair than dO / P~: at the top of the pair the registers are full)
+  auto load_q = [&](int it, PKTileRegs& R) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t ir = (uint32_t)min(it * 64 + srow + t * 32, lim - 1);
+      R.q[t] = (FBL_ATTN_DBGBITS & 16) ? vf[0] : buf_ld16(qr, ir * ldq2 + (uint32_t)(sch * 16), 0);
+    }
+  };
+  auto store_tile = [&](const PKTileRegs& R, int it_i0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      *(bf16x8*)(smem + K_DOS + sb + t * 4096) = R.d[t];
+      *(bf16x8*)(smem + K_QS + sb + t * 4096) = R.q[t];
+      *(bf16x8*)(smem + K_PS + sp + t * (32 * LDP * 2)) = R.p[t];
+    }
+    if (tid < 64) {  // padding and masked queries: lse = +inf in the forward -> P = 0
+      const bool live = it_i0 + tid < lim && R.l < INFINITY;
+      rF[tid] = live ? __builtin_amdgcn_exp2f(R.m - R.l * LOG2E) : 0.f;
+      rD[tid] = live ? R.D : 0.f;
+    }
+  };
+
+  PKTileRegs R;
+  if (nqt > 0) {
+    load_tile(0, R);
+    load_q(0, R);
+  }
+  for (int it = 0; it < nqt; ++it) {
+    const int i0 = it * 64;
+    store_tile(R, i0);
+    __syncthreads();  // (also: every wave is done with the staging tiles of the previous pair)
+    // this pair's table fragments (L2-resident; consumed at the end of the pair) are requested BEFORE the next pair's operands:
+    // vector memory returns in order, so a wait for a fragment requested behind them would wait for their HBM latency too
+    bf16x8 tf0[4], tf1[4], tf2[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (FBL_ATTN_DBGBITS & 1) { tf0[dt] = tf1[dt] = tf2[dt] = vf[0]; continue; }  // (debug builds: no table loads)
+      tf0[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2));
+      tf1[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2 + 64));
+      tf2[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2 + 128));
+    }
+    {  // the next pair's operands fly during this pair's arithmetic.  Unconditional (the last pair re-requests its own tile):
+       // behind a branch the compiler cannot count these requests and every later wait would cover them -- an HBM latency per pair
+      const int itn = min(it + 1, nqt - 1);
+      load_tile(itn, R);
+      load_q(itn, R);
+    }
+
+    bf16x4 dsb[4], pfh[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      union { tr16x4 t; bf16x4 v; } pu;
+      pu.t = lds_tr16((const bf16*)(smem + K_PS + (nt * 16 + g * 4 + (c >> 2)) * (LDP * 2) + (w * 16 + (c & 3) * 4) * 2));
+      const f32x4 f4 = *(const f32x4*)(rF + nt * 16 + g * 4);
+      const f32x4 d4 = *(const f32x4*)(rD + nt * 16 + g * 4);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + K_DOS + nt * 2048 + fb0), vf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + K_DOS + nt * 2048 + fb1), vf[1], acc, 0, 0, 0);
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          uint32_t x, y;
+          attn_drop_block(dkey, (i0 + nt * 16 + g * 4 + bb * 2) >> 1, j >> 1, Sp >> 1, &x, &y);
+          keep[bb * 2] = attn_drop_keep(dkey, x, y, 0, j & 1);
+          keep[bb * 2 + 1] = attn_drop_keep(dkey, x, y, 1, j & 1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = f4[r] != 0.f ? bf2f(pu.v[r]) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
+        dsb[nt][r] = f2bf(pv * (acc[r] * keep[r] - d4[r]) * a.scale);
+        pfh[nt][r] = f2bf(pv * keep[r]);
+      }
+    }
+    // ---- dV^T += dO^T . drop(P) and dK^T += Q^T . dS:  k-slot e of step kk <-> query kk*32 + (e>>2)*16 + g*4 + (e&3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pf, sf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = pfh[2 * kk][e];
+        pf[4 + e] = pfh[2 * kk + 1][e];
+        sf[e] = dsb[2 * kk][e];
+        sf[4 + e] = dsb[2 * kk + 1][e];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int r = g * 4 + (c >> 2);
+        const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        const int o = r * 128 + ((ch ^ (r & 7)) << 4) + sub + kk * 4096;
+        union { tr16x4 h[2]; bf16x8 v; } u, uq;
+        u.h[0] = lds_tr16((const bf16*)(smem + K_DOS + o));
+        u.h[1] = lds_tr16((const bf16*)(smem + K_DOS + o + 2048));
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, dv[dt], 0, 0, 0);
+        if (FBL_ATTN_DBGBITS & 2) continue;  // (debug builds: no Q^T . dS)
+        uq.h[0] = lds_tr16((const bf16*)(smem + K_QS + o));
+        uq.h[1] = lds_tr16((const bf16*)(smem + K_QS + o + 2048));
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uq.v, sf, dk[dt], 0, 0, 0);
+      }
+    }
+    // ---- dS (row-major, over the P~ columns this wave has consumed), dS^T and the sheared copy
+    {
+      bf16* gs = g2 + 64 - (w * 16 + c) + g * 4;  // x of query nt*16 + g*4 + r: + nt*16 + r
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        *(bf16x4*)(dstT + (w * 16 + c) * LDV + nt * 16 + g * 4) = dsb[nt];  // [key][query]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[(nt * 16 + g * 4 + r) * LDP + w * 16 + c] = dsb[nt][r];  // [query][key]
+          if (!(FBL_ATTN_DBGBITS & 4)) gs[nt * 16 + r] = dsb[nt][r];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = srow + t * 32;
+      buf_st16(dSr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * Sp * 2), *(const bf16x8*)(dst + row * LDP + sch * 8));
+      buf_st16(dSTr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * 2), *(const bf16x8*)(dstT + row * LDV + sch * 8));
+    }
+    // ---- dK^T += PQX^T . G2^T over this wave's three k-steps
+    if (!(FBL_ATTN_DBGBITS & 8)) {
+      const bf16x8 gf0 = *(const bf16x8*)(g2 + ks0 * 32 + g * 8);
+      const bf16x8 gf1 = *(const bf16x8*)(g2 + ks0 * 32 + 32 + g * 8);
+      const bf16x8 gf2 = *(const bf16x8*)(g2 + ks0 * 32 + 64 + g * 8);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf0[dt], gf0, dk[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf1[dt], gf1, dk[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf2[dt], gf2, dk[dt], 0, 0, 0);
+    }
+  }
+
+  if (j < lim) {
+    bf16* op = a.dV + (rb + j) * a.lddv + h * 64 + g * 4;
+    bf16* ok = ka.dK + (rb + j) * ka.lddk + h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
+      *(bf16x4*)(ok + dt * 16) = (bf16x4){f2bf(dk[dt][0]), f2bf(dk[dt][1]), f2bf(dk[dt][2]), f2bf(dk[dt][3])};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- kernel BC
 struct ShearArgs {
   const bf16* X;                          // dS (NEG=0) or dS^T (NEG=1): [B,nh,Sp,Sp], rows = output rows
@@ -1164,6 +1444,36 @@ extern "C" int fbl_disent_attn_bwd_dsp(const void* psave, const float* msave, co
   return 0;
 }
 
+extern "C" int fbl_disent_attn_bwd_dspk(const void* psave, const float* msave, const void* q, int64_t ldq, const void* v, int64_t ldv,
+                                        const void* dO, int64_t ldo, const void* pqx, const int32_t* klen, const int32_t* border,
+                                        const float* lse, const float* Dv, float scale, float p_drop, uint64_t seed,
+                                        const uint64_t* seed_dev, void* dK, int64_t lddk, void* dV, int64_t lddv, void* dS, void* dST,
+                                        int B, int S, int Sp, int nh, const int32_t* row0, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if ((ldv % 8) || (ldo % 8) || (ldq % 8) || (lddv % 4) || (lddk % 4)) return FBL_ERR_ALIGN;
+  if (!psave || !msave || !q || !v || !dO || !pqx || !lse || !Dv || !dK || !dV || !dS || !dST) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
+  if (B <= 0 || nh <= 0) return 0;
+  BwdPKArgs a{{(const bf16*)psave, msave, (const bf16*)v, ldv, (const bf16*)dO, ldo, klen, border, lse, Dv, scale, p_drop, seed,
+               seed_dev, (bf16*)dV, lddv, (bf16*)dS, (bf16*)dST, B, S, Sp, nh, row0},
+              (const bf16*)q, ldq, (const bf16*)pqx, (bf16*)dK, lddk};
+  attn_debug_init();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dspk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dspk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(Sp / 64) * nh * B);
+  if (row0)
+    hipLaunchKernelGGL(attn_bwd_dspk_kernel<true>, grid, dim3(256), K_TOTAL, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dspk_kernel<false>, grid, dim3(256), K_TOTAL, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_sh, int64_t y_sb,
                                          int64_t y_sd, const void* PT, const int16_t* relidx, const int32_t* klen,
                                          const int32_t* border, void* out, int64_t ldout, void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S,
@@ -1273,14 +1583,19 @@ extern "C" int fbl_gt_tilemask(const int16_t* relidx, const int32_t* klen, int B
 
 extern "C" int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp,
                                  const void* dO, const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT,
-                                 float* Dv, int B, int S, int Sp, int nh, int span2, const int32_t* row0, void* stream) {
+                                 float* Dv, const int16_t* relidx, void* PQX, void* PKX, int B, int S, int Sp, int nh, int span2,
+                                 const int32_t* row0, void* stream) {
   if (S < 1 || Sp < S || Sp % 64 || span2 <= 0 || span2 % 64) return FBL_ERR_SHAPE;
   if ((ldq % 8) || (ldp % 8) || (ldo % 8)) return FBL_ERR_ALIGN;
+  if ((PQX || PKX) && !relidx) return FBL_ERR_ARG;
+  if (!Dv) return FBL_ERR_ARG;
   if (B <= 0 || nh <= 0) return 0;
+  const int n_tr = (Sp / 64) * nh * B, n_tab = (span2 / 64) * nh, n_x = (2 * Sp / 64) * nh;
   PrepArgs a{(const bf16*)q, (const bf16*)k, ldq, (const bf16*)pq, (const bf16*)pk, ldp, (const bf16*)dO, (const bf16*)O, ldo,
-             (bf16*)QT, (bf16*)KT, (bf16*)PQT, (bf16*)PKT, Dv, B, S, Sp, nh, span2, (Sp / 64) * nh * B, (span2 / 64) * nh, row0};
+             (bf16*)QT, (bf16*)KT, (bf16*)PQT, (bf16*)PKT, Dv, B, S, Sp, nh, span2, KT ? n_tr : 0, QT ? n_tr : 0, PKT ? n_tab : 0,
+             PQT ? n_tab : 0, row0, relidx, (bf16*)PQX, (bf16*)PKX, PQX ? n_x : 0, PKX ? n_x : 0};
   const long n_dot = ((long)B * S * nh * 8 + 255) / 256;
-  const long grid = 2l * a.n_tr + 2l * a.n_tab + n_dot;
+  const long grid = (long)a.n_kt + a.n_qt + a.n_pkt + a.n_pqt + a.n_pqx + a.n_pkx + n_dot;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;

@@ -88,6 +88,25 @@ __device__ __forceinline__ tr16x4 lds_tr16(const bf16* p) {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// Buffer addressing for kernels that stream several tensors per loop iteration: a 128-bit descriptor of a WAVE-UNIFORM base in
+// scalar registers + a 32-bit per-lane byte offset + a scalar byte offset (the per-iteration part) -- no 64-bit per-lane
+// pointers (2 VGPRs and a 64-bit add per stream and iteration otherwise).  The base passes through readfirstlane so that the
+// compiler can prove it uniform (anything derived from blockIdx-dependent LOADS is "divergent" to it and every access would
+// be wrapped in a waterfall loop).  Offsets must stay below 4 GiB from the base.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void buf_st16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bf16x8 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 // Relative-index table padded to the 64-tile grid: idxp[t] = relidx[clamp(t - (Sp - S), 0, 2S-2)] with t = i - j + Sp - 1,
 // so that every (i, j) of a tile (valid or padding) indexes it without a clamp.  2*Sp - 1 <= 1023 entries.
 __device__ __forceinline__ void load_idx_padded(int16_t* idxp, const int16_t* relidx, int S, int Sp, int tid, int nthr) {

@@ -848,7 +848,7 @@ inline int grid1d(long n, int block = 256, int cap = 256 * 16) {
     default: return FBL_ERR_SHAPE;                                                                   \
   }
 
-extern "C" int fbl_abi_version(void) { return 7; }
+extern "C" int fbl_abi_version(void) { return 8; }
 
 extern "C" int fbl_embed_gather(const int64_t* ids, const float* E, const float* vproj, int B, int T, int L, int H,
                                 float* out_t, void* stream) {

@@ -88,7 +88,8 @@ class Engine:
         L.load()
         self.dev = dev
         self.opts = dict(getattr(model, "engine_options", None) or {})
-        unknown = set(self.opts) - {"eager_logits", "side_stream", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group"}
+        unknown = set(self.opts) - {"eager_logits", "side_stream", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group", "attn_save_p",
+                                    "pos_grad_gt", "attn_fused_dk"}
         if unknown:
             raise ValueError(f"unknown engine_options: {sorted(unknown)}")
         self._build_flat()
@@ -135,6 +136,8 @@ class Engine:
         self.attn_save_p = bool(o.get("attn_save_p", True))
         #   pos_grad_gt    True = position-table gradients through G^T and split-K GEMMs (rounds 1-5) instead of fbl_attn_pos_grad
         self.pos_grad_gt = bool(o.get("pos_grad_gt", False))
+        #   attn_fused_dk  False = dK by the separate key-major shear pass (rounds 1-5) instead of inside kernel A (fbl_disent_attn_bwd_dspk)
+        self.attn_fused_dk = bool(o.get("attn_fused_dk", True))
         self.fuse_tail = bool(o.get("fuse_tail", True))
         L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(o.get("dw_group", 16))))  # adapter gradient products per launch (<= 16)

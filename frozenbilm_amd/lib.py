@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FBL_LIB") or os.path.join(HERE, "libfbl.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_GRAD = 0, 1, 2, 3
 AUX_NONE, AUX_ADD_F32, AUX_ADD_BF16, AUX_MUL_DGELU_BF16, AUX_MUL_POS_BF16, AUX_MUL_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 7  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
+ABI_VERSION = 8  # fbl_abi_version() of the library this binding was written against (argument lists change with it)
 
 _vp, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -54,7 +54,9 @@ SIGNATURES = {
                                  _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
-    "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_disent_attn_bwd_dspk": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l, _vp, _l,
+                                      _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _f, _f, _u64, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_dsp": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l, _vp, _vp,
@@ -541,15 +543,22 @@ def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
                                       _p(probs), B, S, nh, _stream()), "fbl_disent_attn_probs")
 
 
-def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=None):
-    """K^T, Q^T (head-major), PK^T, PQ^T and D = rowdot(dO, O) in one launch (see fbl.h)"""
+def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=None, relidx=None, PQX=None, PKX=None):
+    """K^T, Q^T (head-major), PK^T, PQ^T, D = rowdot(dO, O) and the index-expanded tables PQX / PKX [nh,64,2*Sp] in one launch
+    (see fbl.h); every output but Dv may be None"""
     ldq, ldp, ldo = _rows2d(q, "q"), _rows2d(pq, "pq"), _rows2d(dO, "dO")
     assert _rows2d(k, "k") == ldq and _rows2d(pk, "pk") == ldp and _rows2d(O, "O") == ldo
-    for t in (QT, KT, PQT, PKT):
-        _req(t, torch.bfloat16, "transposed output")
-        assert t.is_contiguous()
+    for t in (QT, KT, PQT, PKT, PQX, PKX):
+        if t is not None:
+            _req(t, torch.bfloat16, "transposed output")
+            assert t.is_contiguous()
+    for t in (PQX, PKX):
+        if t is not None:
+            _req(relidx, torch.int16, "relidx")
+            assert t.numel() == nh * 64 * 2 * Sp and relidx.numel() == 2 * S - 1
     _chk(load().fbl_attn_bwd_prep(_p(q), _p(k), ldq, _p(pq), _p(pk), ldp, _p(dO), _p(O), ldo, _p(QT), _p(KT), _p(PQT), _p(PKT),
-                                  _p(Dv), B, S, Sp, nh, span2, _row0(row0, B, True), _stream()), "fbl_attn_bwd_prep")
+                                  _p(Dv), _p(relidx), _p(PQX), _p(PKX), B, S, Sp, nh, span2, _row0(row0, B, True), _stream()),
+         "fbl_attn_bwd_prep")
 
 
 def attn_rowdot(dO, O, out, B, S, nh):
@@ -580,6 +589,19 @@ def disent_attn_bwd_dsp(psave, msave, v, dO, lse, Dv, scale, dV, dS, dST, B, S, 
     _chk(load().fbl_disent_attn_bwd_dsp(_p(psave), _p(msave), _p(v), ldv, _p(dO), ldo, _p(klen), _p(border), _p(lse), _p(Dv),
                                         float(scale), float(p_drop), int(seed), _seed_dev(), _p(dV), lddv, _p(dS), _p(dST),
                                         B, S, Sp, nh, _row0(row0, B, klen), _stream()), "fbl_disent_attn_bwd_dsp")
+
+
+def disent_attn_bwd_dspk(psave, msave, q, v, dO, pqx, lse, Dv, scale, dK, dV, dS, dST, B, S, Sp, nh, p_drop=0.0, seed=0, klen=None,
+                         border=None, row0=None):
+    """kernel A from the saved probabilities with dK = dS^T.Q + G2.PQ formed in place (fbl_disent_attn_bwd_dspk, include/fbl.h)"""
+    _req(psave, torch.bfloat16, "psave"); _req(msave, torch.float32, "msave"); _req(pqx, torch.bfloat16, "pqx")
+    assert psave.is_contiguous() and msave.is_contiguous() and pqx.is_contiguous()
+    assert psave.numel() == B * nh * Sp * Sp and msave.numel() == B * nh * (Sp // 64) * S and pqx.numel() == nh * 64 * 2 * Sp
+    ldq, ldv, ldo, lddk, lddv = _rows2d(q, "q"), _rows2d(v, "v"), _rows2d(dO, "dO"), _rows2d(dK, "dK"), _rows2d(dV, "dV")
+    _chk(load().fbl_disent_attn_bwd_dspk(_p(psave), _p(msave), _p(q), ldq, _p(v), ldv, _p(dO), ldo, _p(pqx), _p(klen), _p(border),
+                                         _p(lse), _p(Dv), float(scale), float(p_drop), int(seed), _seed_dev(), _p(dK), lddk,
+                                         _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, _row0(row0, B, klen), _stream()),
+         "fbl_disent_attn_bwd_dspk")
 
 
 def attn_pos_grad(neg, Xs, Ys, dlo, dcnt, dcnt_max, out, B, S, Sp, nh, rcnt, klen=None, row0=None):

@@ -307,11 +307,15 @@ int fbl_attn_pos_grad(int neg, const void* const* X, const void* const* Y, int64
 int fbl_gt_tilemask(const int16_t* relidx, const int32_t* klen, int B, int S, int Sp, int span2, int neg, int gt_rmin, int gt_rcnt,
                     uint32_t* mask, void* stream);
 /* The preparation of one attention backward as ONE launch: QT / KT = fbl_head_transpose of q / k (head-major
- * [nh,64,B,Sp]), PQT / PKT = the same of the position projections ([nh,64,span2]), Dv = fbl_attn_rowdot(dO, O).
- * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D). */
+ * [nh,64,B,Sp]), PQT / PKT = the same of the position projections ([nh,64,span2]), Dv = fbl_attn_rowdot(dO, O), and the
+ * position tables EXPANDED by the relative-index map for the fused key-major pass (fbl_disent_attn_bwd_dspk):
+ *   PQX[h][d][t] = pq[relidx[clamp(t - Sp + S - 1, 0, 2S-2)]][h*64 + d],  t in [0, 2 Sp)  (t - Sp = delta = i - j),
+ * bf16 [nh,64,2*Sp]; PKX the same of pk.  Every output but Dv is optional (NULL: not produced); PQX / PKX need relidx.
+ * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D),
+ * the c2p / p2c gathers :870-918 (the index map the expansion applies once per table instead of once per score). */
 int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp, const void* dO,
-                      const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT, float* Dv, int B, int S, int Sp,
-                      int nh, int span2, const int32_t* row0, void* stream);
+                      const void* O, int64_t ldo, void* QT, void* KT, void* PQT, void* PKT, float* Dv, const int16_t* relidx,
+                      void* PQX, void* PKX, int B, int S, int Sp, int nh, int span2, const int32_t* row0, void* stream);
 int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t ldq, const void* dO, int64_t ldo,
                            const void* pk, const void* pq, int64_t ldp, const int16_t* relidx, const int32_t* mask, const int32_t* klen,
                            const int32_t* border, const float* lse, const float* Dv,
@@ -329,6 +333,15 @@ int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_
                               void* out, int64_t ldout,
                               void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
                               int span2, const int32_t* row0, const uint32_t* gt_tilemask, void* stream);
+/* fbl_disent_attn_bwd_dsp + the key-major shear pass in one kernel: besides dV, dS and dS^T it forms
+ *   dK = dS^T.Q + G2.PQ  (what fbl_disent_attn_bwd_shear(neg = 1) computes from dS^T) -- the second term as a Toeplitz product
+ * against pqx = the PQX of fbl_attn_bwd_prep (no index table, no scatter); q bf16 rows like v.  dS^T is not read back.
+ * ref: autograd of model/deberta.py:789-818 and of the p2c term :896-918. */
+int fbl_disent_attn_bwd_dspk(const void* psave, const float* msave, const void* q, int64_t ldq, const void* v, int64_t ldv,
+                             const void* dO, int64_t ldo, const void* pqx, const int32_t* klen, const int32_t* border,
+                             const float* lse, const float* Dv, float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                             void* dK, int64_t lddk, void* dV, int64_t lddv, void* dS, void* dST, int B, int S, int Sp, int nh,
+                             const int32_t* row0, void* stream);
 
 /* Cross entropy over rows with label != -100 (mean reduction).  logits fp32 [N, ldv], labels int64 [N].
  * loss_sum_cnt[0] += sum of row losses, [1] += count (a fixed-order fold: reproducible bit for bit); row_lse [N] fp32 out.

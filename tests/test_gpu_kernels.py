@@ -531,6 +531,18 @@ def test_attn_bwd_prep_equals_the_separate_launches(L):
     for a, b_, n in ((QT, QT2, "QT"), (KT, KT2, "KT"), (PQT, PQT2, "PQT"), (PKT, PKT2, "PKT"), (Dv, Dv2, "D")):
         assert torch.equal(a, b_), n
     assert (QT[:, :, :, S:] == 0).all()  # positions beyond S are zero-padded
+    # optional outputs: only what is asked for is written; the index-expanded tables of the fused key-major pass
+    from frozenbilm_amd.model.relpos import rel_index_vector
+    relidx = torch.from_numpy(rel_index_vector(S, 256, 512, 256).copy()).to(DEV)
+    KT3, PKT3, Dv3 = mk(nh, 64, B, Sp), mk(nh, 64, span2), torch.empty(B, nh, S, device=DEV)
+    PQX, PKX = mk(nh, 64, 2 * Sp), mk(nh, 64, 2 * Sp)
+    L.attn_bwd_prep(q, k, pq, pk, dO, O, None, KT3, None, PKT3, Dv3, B, S, Sp, nh, span2, relidx=relidx, PQX=PQX, PKX=PKX)
+    assert torch.equal(KT3, KT2) and torch.equal(PKT3, PKT2) and torch.equal(Dv3, Dv2)
+    t = torch.arange(2 * Sp, device=DEV)
+    rows = relidx[(t - Sp + S - 1).clamp(0, 2 * S - 2)].long()  # table row of delta = t - Sp
+    for X, tab, n in ((PQX, pq, "PQX"), (PKX, pk, "PKX")):
+        ref = tab[rows].view(2 * Sp, nh, 64).permute(1, 2, 0)  # [nh, 64, 2 Sp]
+        assert torch.equal(X, ref.contiguous()), n
 
 
 def test_cross_entropy(L):
@@ -706,7 +718,7 @@ def test_attention_fwd_dropout_rate(L):
     assert ctx.float().std().item() > 1e-3  # not all ones: dropout really dropped something
 
 
-@pytest.mark.parametrize("saved_p", [False, True, "gt_route"], ids=["recompute", "saved_p", "gt_route"])
+@pytest.mark.parametrize("saved_p", [False, True, "gt_route", "separate_dk"], ids=["recompute", "saved_p", "gt_route", "separate_dk"])
 @pytest.mark.parametrize("B,S,nh", [(1, 16, 1), (2, 37, 2), (2, 130, 2), (2, 266, 2), (3, 266, 1), (2, 512, 1), (4, 200, 2)])
 def test_attention_bwd(L, B, S, nh, saved_p):
     """saved_p: kernel A reads the un-normalised probabilities the (training) forward left in HBM (fbl_disent_attn_bwd_dsp)
@@ -724,7 +736,8 @@ def test_attention_bwd(L, B, S, nh, saved_p):
     pqk = (pqk.float() * 0.5).to(BF16)
     klen_t = _klen(mask) if S > 100 else None  # exercise both the dense and the tile-skipping paths
     gt_route = saved_p == "gt_route"  # position-table gradients through G^T + split-K GEMMs (rounds 1-5) instead of fbl_attn_pos_grad
-    saved_p = saved_p is True
+    separate_dk = saved_p == "separate_dk"  # saved probabilities, dK by the key-major shear pass instead of inside kernel A
+    saved_p = saved_p is True or separate_dk
     saved = [] if saved_p else None
     ctx, lse = _run_attn_fwd(L, qkv, pqk, mask, relidx, B, S, nh, klen=klen_t, save_p=saved)
     dctx = bf(rnd(B * S, H, seed=5)).to(BF16)
@@ -747,6 +760,7 @@ def test_attention_bwd(L, B, S, nh, saved_p):
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
     eng.pos_grad_gt = gt_route
+    eng.attn_fused_dk = not separate_dk
     run.klen = klen_t
     run.border = _border(run.klen) if (run.klen is not None and B >= 3) else None  # longest-first dispatch (XCD-aware map at B=4)
     import frozenbilm_amd.attn_bwd as AB
