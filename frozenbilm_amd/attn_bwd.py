@@ -109,7 +109,7 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
             QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
     PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     if fused_dk:
-        PQX = torch.empty(nh, 64, 2 * Sp, dtype=BF16, device=dev)
+        PQX = torch.empty(nh, 2 * Sp, 64, dtype=BF16, device=dev)
     else:
         PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0, relidx=relidx, PQX=PQX)

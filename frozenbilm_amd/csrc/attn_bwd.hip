@@ -62,7 +62,7 @@ struct PrepArgs {
   int B, S, Sp, nh, span2;
   int n_kt, n_qt, n_pkt, n_pqt;  // blocks of the K / Q transposes and of the PK / PQ table transposes (0: output not wanted)
   const int32_t* row0;  // [B+1] packed-row layout of q / k / dO / O (see attn_fwd.hip) or null; the outputs keep [B, S(p)]
-  // tables expanded by the relative-index map (the fused key-/query-major passes): X[h][d][t] = tab[relidx[t - Sp + S - 1]][h*64 + d],
+  // tables expanded by the relative-index map (the fused key-/query-major passes): X[h][t][d] = tab[relidx[t - Sp + S - 1]][h*64 + d],
   // t in [0, 2 Sp) standing for delta = i - j = t - Sp (indices beyond the map's range are clamped: dS is zero there)
   const int16_t* relidx;
   bf16* PQX; bf16* PKX;
@@ -71,20 +71,16 @@ struct PrepArgs {
 
 // vt[h*sh + b*sb + d*sd + s] = v[rb+s, h*64+d] (s < S), 0 for S <= s < Sp: one (64-position tile, head, sample); rb = first
 // row of the sample (b*S in the padded layout), S = number of its rows that exist
-// rowmap (optional): position s reads source row rowmap[clamp(s + map_off, 0, map_hi)] instead of rb + s
 __device__ __forceinline__ void head_transpose_tile(uint32_t* tile, const bf16* v, long ldv, bf16* vt, int S, int Sp, long sh,
-                                                    long sb, long sd, int s0, int h, int b, long rb,
-                                                    const int16_t* rowmap = nullptr, int map_off = 0, int map_hi = 0, int src_rows = 0) {
+                                                    long sb, long sd, int s0, int h, int b, long rb) {
   const int t = threadIdx.x;
   {
     const int row = t >> 2, c0 = (t & 3) * 2;
     const int s = s0 + row;
-    long srow = rb + s;
-    if (rowmap) srow = min((int)rowmap[min(max(s + map_off, 0), map_hi)], src_rows - 1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (s < S) x = *(const uint4*)(v + srow * ldv + h * 64 + (c0 + c) * 8);
+      if (s < S) x = *(const uint4*)(v + (rb + s) * ldv + h * 64 + (c0 + c) * 8);
       uint32_t* d = tile + row * 33 + (c0 + c) * 4;
       d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
     }
@@ -131,13 +127,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(PrepArgs a) {
     return;
   }
   id -= a.n_pkt + a.n_pqt;
-  if (id < a.n_pqx + a.n_pkx) {  // expanded tables [nh][64][2 Sp]
+  if (id < a.n_pqx + a.n_pkx) {  // expanded tables [nh][2 Sp][64]: a row gather, 64 rows x one head per block
     const bool isk = id >= a.n_pqx;
     if (isk) id -= a.n_pqx;
     const int W = 2 * a.Sp, nst = W / 64;
     const int st = id % nst, h = id / nst;
-    head_transpose_tile(tile, isk ? a.pk : a.pq, a.ldp, isk ? a.PKX : a.PQX, W, W, 64l * W, (long)a.nh * 64 * W, W, st * 64, h, 0, 0,
-                        a.relidx, a.S - 1 - a.Sp, 2 * a.S - 2, a.span2);
+    const int t = st * 64 + (threadIdx.x >> 2), c0 = (threadIdx.x & 3) * 2;
+    const int src = min((int)a.relidx[min(max(t - a.Sp + a.S - 1, 0), 2 * a.S - 2)], a.span2 - 1);
+    const bf16* sp = (isk ? a.pk : a.pq) + (long)src * a.ldp + h * 64 + c0 * 8;
+    bf16* dp = (isk ? a.PKX : a.PQX) + ((long)h * W + t) * 64 + c0 * 8;
+    *(uint4*)dp = *(const uint4*)sp;
+    *(uint4*)(dp + 8) = *(const uint4*)(sp + 8);
     return;
   }
   id -= a.n_pqx + a.n_pkx;
@@ -680,14 +680,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dsp_kernel(BwdPArgs a) {
 //    relative-index map (fbl_attn_bwd_prep: PQX[h][d][delta + Sp] = PQ[idx(delta)], so log buckets and the identity band are
 //    one case and the kernel holds no index table).  Each wave writes its 16 keys' dS values a second time into a SHEARED tile
 //    G2[j][x], x = (i - i0) - (j - j0) + 64 (16-bit stores; the zero entries of the parallelogram are written once, before the
-//    loop) and reads aligned 16-byte MFMA B fragments back from its own rows -- no barrier; the A fragments PQX^T[d][delta..+7]
-//    are 16-byte loads of the L2-resident table (2 Sp x 64 per head).  A wave's keys reach 96 of the 128 deltas of a pair:
-//    3 k-steps x 4 MFMAs.
+//    loop) and reads aligned 16-byte MFMA B fragments back from its own rows -- no barrier.  The 128 table rows a pair reaches
+//    are two 64-row blocks of PQX (8 KiB each, contiguous); consecutive pairs share one, so every pair stages ONE new block in
+//    LDS beside Q / dO (ring of two; a first version fetched the A fragments PQX^T[d][delta..+7] straight from a transposed
+//    table: twelve 16-byte loads per lane and pair in 64-byte segments, three times the bytes, 20 of the kernel's 110 us) and
+//    the A fragments are transposing LDS reads.  A wave's keys reach 96 of the 128 deltas of a pair: 3 k-steps x 4 MFMAs.
 // dS / dS^T are still written (fbl_attn_pos_grad and the query-major pass read them).
 struct BwdPKArgs {
   BwdPArgs p;
   const bf16* q; long ldq;   // row-major like v, head h at column h*64
-  const bf16* pqx;           // [nh][64][2 Sp]
+  const bf16* pqx;           // [nh][2 Sp][64]
   bf16* dK; long lddk;
 };
 constexpr int LDG2 = 136;                    // bf16 row stride of the sheared tile (128 used)
@@ -696,12 +698,13 @@ constexpr int K_QS = K_DOS + 8192;           // [64 i][64] bf16 swizzled
 constexpr int K_PS = K_QS + 8192;            // [64 i][LDP] bf16: P~, then (same columns per wave) the dS staging tile
 constexpr int K_STT = K_PS + 64 * LDP * 2;   // dS^T staging [64 j][LDV]
 constexpr int K_G2 = K_STT + 64 * LDV * 2;   // sheared dS^T [64 j][LDG2]
-constexpr int K_ROW = K_G2 + 64 * LDG2 * 2;  // float f[64], D[64]
+constexpr int K_TAB = K_G2 + 64 * LDG2 * 2;  // two [64 t][64] bf16 blocks of PQX, swizzled like the Q tile: block beta in slot beta & 1
+constexpr int K_ROW = K_TAB + 16384;         // float f[64], D[64]
 constexpr int K_TOTAL = K_ROW + 512;
-static_assert(3 * K_TOTAL <= 160 * 1024, "three workgroups per CU");
+static_assert(2 * K_TOTAL <= 160 * 1024, "two workgroups per CU");
 
 struct PKTileRegs {
-  bf16x8 d[2], p[2], q[2];
+  bf16x8 d[2], p[2], q[2], x[2];
   float m, l, D;  // raw: msave, lse, D of query row tid (f = exp2(m - l*log2 e) is formed when the tile is stored: a use right behind
                   // the loads would park wave 0 -- and with it the workgroup's next barrier -- for a full memory latency per pair)
 };
@@ -758,8 +761,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
   // Global addresses as a wave-uniform base (buffer descriptor in scalar registers, advanced per pair by a scalar offset) + a
   // 32-bit lane offset that does not change over the loop: 64-bit per-lane pointers for the seven streams of this kernel cost
   // 24 spilled registers
-  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(ka.pqx + (long)h * 64 * W2 + (Sp - j0 - 64) + ks0 * 32);
-  const uint32_t xo = (uint32_t)((c * W2 + g * 8) * 2);
+  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(ka.pqx + (long)h * W2 * 64);
+  const int beta0 = (Sp - j0 - 64) >> 6;  // first table block of pair 0 (pair it: beta0 + it and the next one)
   const __amdgpu_buffer_rsrc_t dOr = buf_rsrc(a.dO + rb * a.ldo + h * 64);
   const __amdgpu_buffer_rsrc_t qr = buf_rsrc(ka.q + rb * ka.ldq + h * 64);
   const __amdgpu_buffer_rsrc_t pr = buf_rsrc(a.psave + sbase + j0);
@@ -775,6 +778,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
       R.d[t] = buf_ld16(dOr, ir * ldo2 + (uint32_t)(sch * 16), 0);
       R.p[t] = buf_ld16(pr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * Sp * 2));
     }
+    // table block beta0 + it + 1 (block beta0 + it is the previous pair's second one)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) R.x[t] = buf_ld16(xr, (uint32_t)((srow + t * 32) * 128 + sch * 16), (uint32_t)((beta0 + it + 1) * 8192));
     {  // (every wave loads, clamped: no branch, no wait; only wave 0's values are stored)
       const int i = min(i0 + lane, lim - 1);
       const long o = ((long)b * a.nh + h) * S + i;
@@ -796,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
     for (int t = 0; t < 2; ++t) {
       *(bf16x8*)(smem + K_DOS + sb + t * 4096) = R.d[t];
       *(bf16x8*)(smem + K_QS + sb + t * 4096) = R.q[t];
+      *(bf16x8*)(smem + K_TAB + (((it_i0 >> 6) + beta0 + 1) & 1) * 8192 + sb + t * 4096) = R.x[t];
       *(bf16x8*)(smem + K_PS + sp + t * (32 * LDP * 2)) = R.p[t];
     }
     if (tid < 64) {  // padding and masked queries: lse = +inf in the forward -> P = 0
@@ -809,21 +816,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
   if (nqt > 0) {
     load_tile(0, R);
     load_q(0, R);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)  // block beta0 (pair 0's first one)
+      *(bf16x8*)(smem + K_TAB + (beta0 & 1) * 8192 + sb + t * 4096) =
+          buf_ld16(xr, (uint32_t)((srow + t * 32) * 128 + sch * 16), (uint32_t)(beta0 * 8192));
   }
   for (int it = 0; it < nqt; ++it) {
     const int i0 = it * 64;
     store_tile(R, i0);
     __syncthreads();  // (also: every wave is done with the staging tiles of the previous pair)
-    // this pair's table fragments (L2-resident; consumed at the end of the pair) are requested BEFORE the next pair's operands:
-    // vector memory returns in order, so a wait for a fragment requested behind them would wait for their HBM latency too
-    bf16x8 tf0[4], tf1[4], tf2[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      if (FBL_ATTN_DBGBITS & 1) { tf0[dt] = tf1[dt] = tf2[dt] = vf[0]; continue; }  // (debug builds: no table loads)
-      tf0[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2));
-      tf1[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2 + 64));
-      tf2[dt] = buf_ld16(xr, xo + (uint32_t)(dt * 16 * W2 * 2), (uint32_t)(i0 * 2 + 128));
-    }
     {  // the next pair's operands fly during this pair's arithmetic.  Unconditional (the last pair re-requests its own tile):
        // behind a branch the compiler cannot count these requests and every later wait would cover them -- an HBM latency per pair
       const int itn = min(it + 1, nqt - 1);
@@ -897,24 +898,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
         }
       }
     }
+    // ---- dK^T += PQX^T . G2^T over this wave's three k-steps (before the barrier: the next pair's staging overwrites the older
+    //      table block; the sheared rows are this wave's own).  A fragment of k-step ks, column tile dt: table rows x = ks*32 + g*8
+    //      + {0..7} of the window (block x >> 6), column d = dt*16 + c -- two transposing reads of four rows each
+    if (!(FBL_ATTN_DBGBITS & 8)) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int x0 = (ks0 + u) * 32 + g * 8;  // (+ c >> 2: the row this lane addresses)
+        const int slot = (((i0 >> 6) + beta0 + (x0 >> 6)) & 1) * 8192;
+        const int r = (x0 & 63) + (c >> 2);
+        const bf16x8 gf = *(const bf16x8*)(g2 + (ks0 + u) * 32 + g * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+          union { tr16x4 h[2]; bf16x8 v; } ut;
+          ut.h[0] = lds_tr16((const bf16*)(smem + K_TAB + slot + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
+          ut.h[1] = lds_tr16((const bf16*)(smem + K_TAB + slot + (r + 4) * 128 + ((ch ^ ((r + 4) & 7)) << 4) + sub));
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ut.v, gf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = srow + t * 32;
       buf_st16(dSr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * Sp * 2), *(const bf16x8*)(dst + row * LDP + sch * 8));
       buf_st16(dSTr, po + (uint32_t)(t * 32 * Sp * 2), (uint32_t)(i0 * 2), *(const bf16x8*)(dstT + row * LDV + sch * 8));
-    }
-    // ---- dK^T += PQX^T . G2^T over this wave's three k-steps
-    if (!(FBL_ATTN_DBGBITS & 8)) {
-      const bf16x8 gf0 = *(const bf16x8*)(g2 + ks0 * 32 + g * 8);
-      const bf16x8 gf1 = *(const bf16x8*)(g2 + ks0 * 32 + 32 + g * 8);
-      const bf16x8 gf2 = *(const bf16x8*)(g2 + ks0 * 32 + 64 + g * 8);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf0[dt], gf0, dk[dt], 0, 0, 0);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf1[dt], gf1, dk[dt], 0, 0, 0);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf2[dt], gf2, dk[dt], 0, 0, 0);
     }
   }
 

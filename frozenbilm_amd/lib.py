@@ -544,7 +544,7 @@ def disent_attn_probs(q, k, pk, pq, relidx, mask, lse, scale, probs, B, S, nh):
 
 
 def attn_bwd_prep(q, k, pq, pk, dO, O, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=None, relidx=None, PQX=None, PKX=None):
-    """K^T, Q^T (head-major), PK^T, PQ^T, D = rowdot(dO, O) and the index-expanded tables PQX / PKX [nh,64,2*Sp] in one launch
+    """K^T, Q^T (head-major), PK^T, PQ^T, D = rowdot(dO, O) and the index-expanded tables PQX / PKX [nh,2*Sp,64] in one launch
     (see fbl.h); every output but Dv may be None"""
     ldq, ldp, ldo = _rows2d(q, "q"), _rows2d(pq, "pq"), _rows2d(dO, "dO")
     assert _rows2d(k, "k") == ldq and _rows2d(pk, "pk") == ldp and _rows2d(O, "O") == ldo

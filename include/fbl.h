@@ -309,8 +309,8 @@ int fbl_gt_tilemask(const int16_t* relidx, const int32_t* klen, int B, int S, in
 /* The preparation of one attention backward as ONE launch: QT / KT = fbl_head_transpose of q / k (head-major
  * [nh,64,B,Sp]), PQT / PKT = the same of the position projections ([nh,64,span2]), Dv = fbl_attn_rowdot(dO, O), and the
  * position tables EXPANDED by the relative-index map for the fused key-major pass (fbl_disent_attn_bwd_dspk):
- *   PQX[h][d][t] = pq[relidx[clamp(t - Sp + S - 1, 0, 2S-2)]][h*64 + d],  t in [0, 2 Sp)  (t - Sp = delta = i - j),
- * bf16 [nh,64,2*Sp]; PKX the same of pk.  Every output but Dv is optional (NULL: not produced); PQX / PKX need relidx.
+ *   PQX[h][t][d] = pq[relidx[clamp(t - Sp + S - 1, 0, 2S-2)]][h*64 + d],  t in [0, 2 Sp)  (t - Sp = delta = i - j),
+ * bf16 [nh,2*Sp,64]; PKX the same of pk.  Every output but Dv is optional (NULL: not produced); PQX / PKX need relidx.
  * ref: transpose_for_scores model/deberta.py:712-715 (position-contiguous operand copies), XSoftmax.backward :134-138 (D),
  * the c2p / p2c gathers :870-918 (the index map the expansion applies once per table instead of once per score). */
 int fbl_attn_bwd_prep(const void* q, const void* k, int64_t ldq, const void* pq, const void* pk, int64_t ldp, const void* dO,

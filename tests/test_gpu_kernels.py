@@ -535,14 +535,14 @@ def test_attn_bwd_prep_equals_the_separate_launches(L):
     from frozenbilm_amd.model.relpos import rel_index_vector
     relidx = torch.from_numpy(rel_index_vector(S, 256, 512, 256).copy()).to(DEV)
     KT3, PKT3, Dv3 = mk(nh, 64, B, Sp), mk(nh, 64, span2), torch.empty(B, nh, S, device=DEV)
-    PQX, PKX = mk(nh, 64, 2 * Sp), mk(nh, 64, 2 * Sp)
+    PQX, PKX = mk(nh, 2 * Sp, 64), mk(nh, 2 * Sp, 64)
     L.attn_bwd_prep(q, k, pq, pk, dO, O, None, KT3, None, PKT3, Dv3, B, S, Sp, nh, span2, relidx=relidx, PQX=PQX, PKX=PKX)
     assert torch.equal(KT3, KT2) and torch.equal(PKT3, PKT2) and torch.equal(Dv3, Dv2)
     t = torch.arange(2 * Sp, device=DEV)
     rows = relidx[(t - Sp + S - 1).clamp(0, 2 * S - 2)].long()  # table row of delta = t - Sp
     for X, tab, n in ((PQX, pq, "PQX"), (PKX, pk, "PKX")):
-        ref = tab[rows].view(2 * Sp, nh, 64).permute(1, 2, 0)  # [nh, 64, 2 Sp]
-        assert torch.equal(X, ref.contiguous()), n
+        ref = tab[rows].view(2 * Sp, nh, 64).permute(1, 0, 2)  # [nh, 2 Sp, 64]
+        assert torch.equal(X.view(nh, 2 * Sp, 64), ref.contiguous()), n
 
 
 def test_cross_entropy(L):

@@ -77,7 +77,7 @@ def fwd_save():  # the training forward: also leaves the un-normalised probabili
                       seed=7, border=border, lin=LIN, psave=psave, msave=msave)
 
 
-PQX = torch.empty(nh, 64, 2 * Sp, dtype=torch.bfloat16, device=dev)
+PQX = torch.empty(nh, 2 * Sp, 64, dtype=torch.bfloat16, device=dev)
 
 
 def prep_x():  # the preparation of the fused route: K^T, PK^T (query-major shear pass), D, PQX
