@@ -99,20 +99,27 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
     # round 6: with the forward's probabilities saved, kernel A forms dK itself (fbl_disent_attn_bwd_dspk) -- no key-major shear
     # pass, no Q^T / PQ^T copies; engine_options["attn_fused_dk"] = False keeps the separate pass
     fused_dk = getattr(sv, "psave", None) is not None and not use_gt and bool(getattr(eng, "attn_fused_dk", True))
+    # the query-major half in Toeplitz form (fbl_disent_attn_bwd_dq) instead of the scatter-based shear pass: no K^T / PK^T copies;
+    # engine_options["attn_toeplitz_dq"] = False keeps the shear pass
+    toep_dq = not use_gt and bool(getattr(eng, "attn_toeplitz_dq", True))
     G1T = G2T = None
-    QT = PQT = PQX = None
+    QT = KT = PQT = PKT = PQX = PKX = None
     if bufs is not None and use_gt:
         G1T, G2T, QT, KT = bufs
     else:
-        KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
+        if not toep_dq:
+            KT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
         if not fused_dk:
             QT = torch.empty(nh, 64, B, Sp, dtype=BF16, device=dev)
-    PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
+    if toep_dq:
+        PKX = torch.empty(nh, 2 * Sp, 64, dtype=BF16, device=dev)
+    else:
+        PKT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
     if fused_dk:
         PQX = torch.empty(nh, 2 * Sp, 64, dtype=BF16, device=dev)
     else:
         PQT = torch.empty(nh, 64, span2, dtype=BF16, device=dev)
-    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0, relidx=relidx, PQX=PQX)
+    L.attn_bwd_prep(q, k, pq, pk, dctx, sv.ctx, QT, KT, PQT, PKT, Dv, B, S, Sp, nh, span2, row0=row0, relidx=relidx, PQX=PQX, PKX=PKX)
     dS = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     dST = torch.empty(B, nh, Sp, Sp, dtype=BF16, device=dev)
     # only the rows of G^T inside the range of relidx can be non-zero: write / contract just those
@@ -143,8 +150,11 @@ def disent_attn_bwd(eng, run, sv, dctx, dqkv, dpqk, defer_pos=False, bufs=None):
             G2T.fill_(float("nan"))
         # (without klen the products read every row of G^T: everything outside the windows must then be zero-filled)
         m1, m2 = gt_tilemasks(eng, run) if klen is not None else (None, None)
-    L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
-                            lin=lin, border=border, row0=row0, tilemask=m1)
+    if toep_dq:
+        L.disent_attn_bwd_dq(dS, k, PKX, dqkv[:, :H], B, S, Sp, nh, klen=klen, border=border, row0=row0)
+    else:
+        L.disent_attn_bwd_shear(0, dS, KT, PKT, relidx, dqkv[:, :H], G1T, B, S, Sp, nh, span2, klen=klen, rmin=rmin, rcnt=rcnt,
+                                lin=lin, border=border, row0=row0, tilemask=m1)
     if not fused_dk:
         L.disent_attn_bwd_shear(1, dST, QT, PQT, relidx, dqkv[:, H:2 * H], G2T, B, S, Sp, nh, span2, klen=klen, rmin=rmin,
                                 rcnt=rcnt, lin=lin, border=border, row0=row0, tilemask=m2)

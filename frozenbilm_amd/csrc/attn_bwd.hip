@@ -938,6 +938,142 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- query-major pass (Toeplitz form)
+// dQ_i = sum_j dS[i,j] K_j + sum_j dS[i,j] PK[idx(i-j)]  from the dS tensor kernel A wrote -- what attn_bwd_shear<NEG = 0> computes by
+// scattering dS into index space (LDS stores / atomics per element, an index table, a table GEMM over the whole window): here, like
+// the key-major half inside attn_bwd_dspk, the position term is a Toeplitz product against PKX (the table expanded by the index
+// map): the 64 x 64 dS tile of a pair is stored twice by the wave that owns its rows -- row-major (MFMA B fragments of dS.K) and
+// sheared, G1[i][x], x = (i - i0) - (j - j0) + 64 -- and the 128 table rows of the pair are two 64-row blocks of PKX of which
+// consecutive pairs share one.  One workgroup = (sample, head, 64 queries); it walks the key tiles below the sample's length.
+// The dS rows and the sheared rows are wave-private (no barrier between their store and their use); the K tile and the table
+// blocks are shared: two barriers per pair.
+struct BwdQArgs {
+  const bf16* dS;            // [B,nh,Sp,Sp]
+  const bf16* k; long ldk;   // row-major rows b*S + s (or packed), head h at column h*64
+  const bf16* pkx;           // [nh][2 Sp][64]
+  const int32_t* klen; const int32_t* border;
+  bf16* dQ; long lddq;
+  int B, S, Sp, nh;
+  const int32_t* row0;
+};
+constexpr int LDG1 = 104;                    // bf16 row stride of the sheared tile: the 96 columns x - 32*ks0 a wave's rows reach
+constexpr int Q_DS = 0;                      // [64 i][64 j] bf16 swizzled (rows wave-private)
+constexpr int Q_KS = Q_DS + 8192;            // [64 j][64 d] bf16 swizzled
+constexpr int Q_G1 = Q_KS + 8192;            // [64 i][LDG1]
+constexpr int Q_TAB = Q_G1 + 64 * LDG1 * 2;  // two [64 t][64] blocks of PKX: block beta in slot beta & 1
+constexpr int Q_TOTAL = Q_TAB + 16384;
+static_assert(3 * Q_TOTAL <= 160 * 1024, "three workgroups per CU");
+
+template <bool PACKED = false>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdQArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int S = a.S, Sp = a.Sp;
+  const WgCoord wc = wg_coord(Sp / 64, a.nh, a.B, a.border);
+  const int i0 = wc.x * 64, h = wc.h, b = wc.b;
+  const int i = i0 + w * 16 + c;  // this lane's query
+  const long rb = PACKED ? (long)a.row0[b] : (long)b * S;
+  const int lim = PACKED ? min(a.row0[b + 1] - a.row0[b], S) : S;
+  const int kl = a.klen ? min(a.klen[b], S) : S;
+  const int nkt = (i0 < kl) ? (kl + 63) / 64 : 0;  // rows beyond the last valid position: dS = 0 (never written) -> dQ = 0
+  const int srow = tid >> 3, sch = tid & 7;
+  const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);  // K / table staging slot of row srow + 32 t: + t*4096
+  const int ks0 = (w < 2) ? 0 : 1;  // this wave's rows reach x in [16 w + 1, 16 w + 79]: three of the four 32-wide k-steps
+  bf16* g1 = (bf16*)(smem + Q_G1) + (w * 16 + c) * LDG1;  // this lane's row of the sheared tile (column x - 32*ks0)
+  const int wr = w * 16 + c;                              // its row of the tile
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nkt > 0) {  // the sheared tile starts as zeros (the loop only rewrites the entries inside the parallelogram)
+    for (int t = tid; t < (64 * LDG1 * 2) / 16; t += 256) *(bf16x8*)(smem + Q_G1 + t * 16) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+  }
+
+  const long sbase = ((long)b * a.nh + h) * Sp * Sp;
+  const __amdgpu_buffer_rsrc_t sr = buf_rsrc(a.dS + sbase + (long)i0 * Sp);
+  const __amdgpu_buffer_rsrc_t kr = buf_rsrc(a.k + rb * a.ldk + h * 64);
+  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(a.pkx + (long)h * 2 * Sp * 64);
+  const uint32_t so = (uint32_t)((wr * Sp + g * 16) * 2);  // row wr, columns g*16 .. +15 of the tile
+  const uint32_t ldk2 = (uint32_t)(a.ldk * 2);
+  const int beta0 = (i0 - 64 + Sp) >> 6;  // first table block of the pair with key tile 0; key tile jt: blocks beta0 - jt, + 1
+
+  struct Regs { bf16x8 s[2], k[2], x[2]; } R;
+  auto load_pair = [&](int jt) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      R.s[t] = buf_ld16(sr, so + (uint32_t)(t * 16), (uint32_t)(jt * 128));
+      const uint32_t jr = (uint32_t)min(jt * 64 + srow + t * 32, lim - 1);
+      R.k[t] = buf_ld16(kr, jr * ldk2 + (uint32_t)(sch * 16), 0);
+      R.x[t] = buf_ld16(xr, (uint32_t)((srow + t * 32) * 128 + sch * 16), (uint32_t)((beta0 - jt) * 8192));  // the pair's LOWER block
+    }
+  };
+  if (nkt > 0) {
+    load_pair(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)  // pair 0's upper block
+      *(bf16x8*)(smem + Q_TAB + ((beta0 + 1) & 1) * 8192 + sb + t * 4096) =
+          buf_ld16(xr, (uint32_t)((srow + t * 32) * 128 + sch * 16), (uint32_t)((beta0 + 1) * 8192));
+  }
+  for (int jt = 0; jt < nkt; ++jt) {
+    // ---- staging: K tile and the new table block (shared), this wave's dS rows row-major and sheared (private)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      *(bf16x8*)(smem + Q_KS + sb + t * 4096) = R.k[t];
+      *(bf16x8*)(smem + Q_TAB + ((beta0 - jt) & 1) * 8192 + sb + t * 4096) = R.x[t];
+      *(bf16x8*)(smem + Q_DS + wr * 128 + (((2 * g + t) ^ (wr & 7)) << 4)) = R.s[t];
+    }
+    {
+      // element e of R.s[t]: key column cj = g*16 + t*8 + e -> x = wr - cj + 64, stored at column x - 32*ks0
+      bf16* gs = g1 + wr + 64 - g * 16 - ks0 * 32;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gs[-(t * 8 + e)] = R.s[t][e];
+    }
+    __syncthreads();
+    load_pair(min(jt + 1, nkt - 1));  // (unconditional: see attn_bwd_dspk)
+    // ---- dQ^T += K^T . dS^T: A = transposing reads of the K tile, B = this lane's dS row (k = key)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int rk = kk * 32 + g * 8 + (c >> 2);
+      const bf16x8 sf = *(const bf16x8*)(smem + Q_DS + wr * 128 + (((kk * 4 + g) ^ (wr & 7)) << 4));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        union { tr16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = lds_tr16((const bf16*)(smem + Q_KS + rk * 128 + ((ch ^ (rk & 7)) << 4) + sub));
+        u.h[1] = lds_tr16((const bf16*)(smem + Q_KS + (rk + 4) * 128 + ((ch ^ ((rk + 4) & 7)) << 4) + sub));
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, sf, dq[dt], 0, 0, 0);
+      }
+    }
+    // ---- dQ^T += PKX^T . G1^T over this wave's three k-steps
+#pragma unroll
+    for (int u3 = 0; u3 < 3; ++u3) {
+      const int x0 = (ks0 + u3) * 32 + g * 8;
+      const int slot = ((beta0 - jt + (x0 >> 6)) & 1) * 8192;
+      const int r = (x0 & 63) + (c >> 2);
+      const bf16x8 gf = *(const bf16x8*)(g1 + u3 * 32 + g * 8);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
+        union { tr16x4 h[2]; bf16x8 v; } ut;
+        ut.h[0] = lds_tr16((const bf16*)(smem + Q_TAB + slot + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
+        ut.h[1] = lds_tr16((const bf16*)(smem + Q_TAB + slot + (r + 4) * 128 + ((ch ^ ((r + 4) & 7)) << 4) + sub));
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ut.v, gf, dq[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with the K tile and the older table block
+  }
+  if (i < lim) {
+    bf16* op = a.dQ + (rb + i) * a.lddq + h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *(bf16x4*)(op + dt * 16) = (bf16x4){f2bf(dq[dt][0]), f2bf(dq[dt][1]), f2bf(dq[dt][2]), f2bf(dq[dt][3])};
+  }
+}
+
 // ------------------------------------------------------------------------------------------- kernel BC
 struct ShearArgs {
   const bf16* X;                          // dS (NEG=0) or dS^T (NEG=1): [B,nh,Sp,Sp], rows = output rows
@@ -1479,6 +1615,31 @@ extern "C" int fbl_disent_attn_bwd_dspk(const void* psave, const float* msave, c
     hipLaunchKernelGGL(attn_bwd_dspk_kernel<true>, grid, dim3(256), K_TOTAL, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_dspk_kernel<false>, grid, dim3(256), K_TOTAL, (hipStream_t)stream, a);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fbl_disent_attn_bwd_dq(const void* dS, const void* k, int64_t ldk, const void* pkx, const int32_t* klen,
+                                      const int32_t* border, void* dQ, int64_t lddq, int B, int S, int Sp, int nh,
+                                      const int32_t* row0, void* stream) {
+  if (S < 1 || S > 512 || Sp < S || Sp % 64) return FBL_ERR_SHAPE;
+  if ((ldk % 8) || (lddq % 4)) return FBL_ERR_ALIGN;
+  if (!dS || !k || !pkx || !dQ) return FBL_ERR_ARG;
+  if (row0 && !klen) return FBL_ERR_ARG;
+  if (B <= 0 || nh <= 0) return 0;
+  BwdQArgs a{(const bf16*)dS, (const bf16*)k, ldk, (const bf16*)pkx, klen, border, (bf16*)dQ, lddq, B, S, Sp, nh, row0};
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(Sp / 64) * nh * B);
+  if (row0)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), Q_TOTAL, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), Q_TOTAL, (hipStream_t)stream, a);
   FBL_CHECK_LAUNCH();
   return 0;
 }

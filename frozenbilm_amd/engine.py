@@ -89,7 +89,7 @@ class Engine:
         self.dev = dev
         self.opts = dict(getattr(model, "engine_options", None) or {})
         unknown = set(self.opts) - {"eager_logits", "side_stream", "fold_dx", "dw_on_side", "fuse_tail", "merge", "dw_group", "attn_save_p",
-                                    "pos_grad_gt", "attn_fused_dk"}
+                                    "pos_grad_gt", "attn_fused_dk", "attn_toeplitz_dq"}
         if unknown:
             raise ValueError(f"unknown engine_options: {sorted(unknown)}")
         self._build_flat()
@@ -138,6 +138,8 @@ class Engine:
         self.pos_grad_gt = bool(o.get("pos_grad_gt", False))
         #   attn_fused_dk  False = dK by the separate key-major shear pass (rounds 1-5) instead of inside kernel A (fbl_disent_attn_bwd_dspk)
         self.attn_fused_dk = bool(o.get("attn_fused_dk", True))
+        #   attn_toeplitz_dq  False = dQ by the scatter-based query-major shear pass (rounds 1-5) instead of fbl_disent_attn_bwd_dq
+        self.attn_toeplitz_dq = bool(o.get("attn_toeplitz_dq", True))
         self.fuse_tail = bool(o.get("fuse_tail", True))
         L.exclude_from_aux(self.side)  # side-stream GEMMs never fork into the aux stream of the main stream's GEMMs
         self.dw_group = max(1, min(L.ADW_MAX_ADAPTERS, int(o.get("dw_group", 16))))  # adapter gradient products per launch (<= 16)

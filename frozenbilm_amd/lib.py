@@ -55,6 +55,7 @@ SIGNATURES = {
     "fbl_disent_attn_probs": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "fbl_attn_rowdot": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp]),
     "fbl_attn_bwd_prep": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "fbl_disent_attn_bwd_dq": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_dspk": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _f, _f, _u64, _vp, _vp, _l, _vp, _l,
                                       _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fbl_disent_attn_bwd_ds": (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -602,6 +603,15 @@ def disent_attn_bwd_dspk(psave, msave, q, v, dO, pqx, lse, Dv, scale, dK, dV, dS
                                          _p(lse), _p(Dv), float(scale), float(p_drop), int(seed), _seed_dev(), _p(dK), lddk,
                                          _p(dV), lddv, _p(dS), _p(dST), B, S, Sp, nh, _row0(row0, B, klen), _stream()),
          "fbl_disent_attn_bwd_dspk")
+
+
+def disent_attn_bwd_dq(dS, k, pkx, dQ, B, S, Sp, nh, klen=None, border=None, row0=None):
+    """dQ = dS.K + G1.PK in Toeplitz form (fbl_disent_attn_bwd_dq, include/fbl.h)"""
+    _req(dS, torch.bfloat16, "dS"); _req(pkx, torch.bfloat16, "pkx")
+    assert dS.is_contiguous() and pkx.is_contiguous() and dS.numel() == B * nh * Sp * Sp and pkx.numel() == nh * 2 * Sp * 64
+    ldk, lddq = _rows2d(k, "k"), _rows2d(dQ, "dQ")
+    _chk(load().fbl_disent_attn_bwd_dq(_p(dS), _p(k), ldk, _p(pkx), _p(klen), _p(border), _p(dQ), lddq, B, S, Sp, nh,
+                                       _row0(row0, B, klen), _stream()), "fbl_disent_attn_bwd_dq")
 
 
 def attn_pos_grad(neg, Xs, Ys, dlo, dcnt, dcnt_max, out, B, S, Sp, nh, rcnt, klen=None, row0=None):

@@ -333,6 +333,12 @@ int fbl_disent_attn_bwd_shear(int neg, const void* X, const void* YT, int64_t y_
                               void* out, int64_t ldout,
                               void* GT, int gt_rmin, int gt_rcnt, int lin_span, int B, int S, int Sp, int nh,
                               int span2, const int32_t* row0, const uint32_t* gt_tilemask, void* stream);
+/* The query-major half in Toeplitz form: dQ = dS.K + G1.PK (what fbl_disent_attn_bwd_shear(neg = 0) computes) from the dS of
+ * fbl_disent_attn_bwd_ds / _dsp / _dspk, k bf16 rows, and pkx = the PKX of fbl_attn_bwd_prep -- no index table, no scatter, no
+ * transposed copies of K / PK.  klen / border / row0 (packed rows of k and dQ) as above.
+ * ref: autograd of model/deberta.py:756-765 (QK^T) and of the c2p term :870-894. */
+int fbl_disent_attn_bwd_dq(const void* dS, const void* k, int64_t ldk, const void* pkx, const int32_t* klen, const int32_t* border,
+                           void* dQ, int64_t lddq, int B, int S, int Sp, int nh, const int32_t* row0, void* stream);
 /* fbl_disent_attn_bwd_dsp + the key-major shear pass in one kernel: besides dV, dS and dS^T it forms
  *   dK = dS^T.Q + G2.PQ  (what fbl_disent_attn_bwd_shear(neg = 1) computes from dS^T) -- the second term as a Toeplitz product
  * against pqx = the PQX of fbl_attn_bwd_prep (no index table, no scatter); q bf16 rows like v.  dS^T is not read back.

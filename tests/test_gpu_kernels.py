@@ -760,7 +760,7 @@ def test_attention_bwd(L, B, S, nh, saved_p):
     eng.cfg = _t.SimpleNamespace(position_buckets=256, max_rel=512, att_span=256)  # enables the relidx-range / injective-store paths
     run.B, run.S, run.mask_i32, run.p_att = B, S, mask.view(-1), 0.0
     eng.pos_grad_gt = gt_route
-    eng.attn_fused_dk = not separate_dk
+    eng.attn_fused_dk = eng.attn_toeplitz_dq = not separate_dk  # "separate_dk": both shear passes of rounds 1-5
     run.klen = klen_t
     run.border = _border(run.klen) if (run.klen is not None and B >= 3) else None  # longest-first dispatch (XCD-aware map at B=4)
     import frozenbilm_amd.attn_bwd as AB

@@ -84,6 +84,17 @@ def prep_x():  # the preparation of the fused route: K^T, PK^T (query-major shea
     L.attn_bwd_prep(q, k, pq, pk, dctx, ctx, None, KT, None, PKT, Dv, B, S, Sp, nh, span2, relidx=relidx, PQX=PQX)
 
 
+PKX = torch.empty(nh, 2 * Sp, 64, dtype=torch.bfloat16, device=dev)
+
+
+def prep_xx():  # the preparation when both halves run in Toeplitz form: D, PQX, PKX
+    L.attn_bwd_prep(q, k, pq, pk, dctx, ctx, None, None, None, None, Dv, B, S, Sp, nh, span2, relidx=relidx, PQX=PQX, PKX=PKX)
+
+
+def bwd_dq():
+    L.disent_attn_bwd_dq(dS, k, PKX, dqkv[:, :H], B, S, Sp, nh, klen=klen, border=border)
+
+
 def bwd_pk():  # kernel A from the saved probabilities + dK in place
     L.disent_attn_bwd_dspk(psave, msave, q, v, dctx, PQX, lse, Dv, scale, dqkv[:, H:2 * H], dqkv[:, 2 * H:], dS, dST, B, S, Sp, nh,
                            p_drop=P, seed=7, klen=klen, border=border)
@@ -176,12 +187,13 @@ def shear_both():  # the two shear passes are independent: second one on a side 
 fwd_save()
 prep()
 prep_x()
+prep_xx()
 bwd_p()
 res = {n: timeit(f) for n, f in (("fwd", fwd), ("fwd_save", fwd_save), ("prep", prep), ("prep_x", prep_x), ("bwd_a", bwd_a), ("bwd_p", bwd_p),
-                                 ("bwd_pk", bwd_pk),
+                                 ("bwd_pk", bwd_pk), ("prep_xx", prep_xx), ("bwd_dq", bwd_dq),
                                  ("shear0", shear0), ("shear1", shear1), ("shear0_nogt", shear0n), ("shear1_nogt", shear1n),
                                  (f"posgrad_x{EPG}", posgrad), ("shear0||1", shear_both))}
 npairs = int(sum(((int(k) + 63) // 64) ** 2 for k in klen.tolist()) * nh)
 tag = f"pairs={npairs} order={order} S={S} B={B} plainmap={os.environ.get('FBL_ATTN_PLAINMAP', '0')} dbg={os.environ.get('FBL_ATTN_DBG', '0')} occ={os.environ.get('FBL_ATTN_OCC', '-')} lin={LIN}"
 print(tag + " | " + "  ".join(f"{n} {t:.1f}us" for n, t in res.items()) + f"  | bwd total (recompute) {res['prep'] + res['bwd_a'] + res['shear0'] + res['shear1']:.1f}us, (saved P) "
-      f"{res['prep'] + res['bwd_p'] + res['shear0'] + res['shear1']:.1f}us, (fused dK) {res['prep_x'] + res['bwd_pk'] + res['shear0_nogt']:.1f}us")
+      f"{res['prep'] + res['bwd_p'] + res['shear0'] + res['shear1']:.1f}us, (fused dK) {res['prep_x'] + res['bwd_pk'] + res['shear0_nogt']:.1f}us, (+ Toeplitz dQ) {res['prep_xx'] + res['bwd_pk'] + res['bwd_dq']:.1f}us")
