@@ -71,7 +71,7 @@ __host__ __device__ constexpr int sm_total(int Sp) { return SM_IDX + 2 * Sp * 2;
 
 struct TileRegs {  // one key tile in flight: 4 x 16 B per thread
   bf16x8 k[2], v[2];
-  float km;
+  int km;  // mask word of key j0 + lane
 };
 
 // PACKED: q / k / v / ctx rows follow AttnArgs::row0 (ragged batches without their padding rows); mask and lse keep the
@@ -133,19 +133,17 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
       R.k[t] = *(const bf16x8*)(a.k + (rb + j) * a.ldk + h * 64 + sch * 8);
       R.v[t] = *(const bf16x8*)(a.v + (rb + j) * a.ldv + h * 64 + sch * 8);
     }
-    R.km = 0.f;
-    if (tid < 64) {
-      const int j = j0 + tid;
-      R.km = (j < S && a.mask[(long)b * S + min(j, S - 1)] != 0) ? 1.f : 0.f;
-    }
+    // (every wave loads the mask word of key j0 + lane, clamped, and nothing here USES it: a use inside a tid < 64 branch would
+    //  park wave 0 -- and with it the workgroup's next barrier -- until the K / V requests in front of it have returned)
+    R.km = a.mask[(long)b * S + min(j0 + lane, S - 1)];
   };
-  auto store_tile = [&](const TileRegs& R) {
+  auto store_tile = [&](const TileRegs& R, int j0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       *(bf16x8*)(smem + SM_KS + sb + t * 4096) = R.k[t];
       *(bf16x8*)(smem + SM_VS + sb + t * 4096) = R.v[t];
     }
-    if (tid < 64) kms[tid] = R.km;
+    if (tid < 64) kms[tid] = (j0 + tid < S && R.km != 0) ? 1.f : 0.f;
   };
 
   TileRegs R;
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
       }
     }
     if (!PF) load_tile(jt, R);  // no register prefetch: the other workgroups of the CU cover the load latency
-    store_tile(R);
+    store_tile(R, j0);
     __syncthreads();  // K / V tile visible
 
     // ---- (1) content scores, transposed: sacc[nt][r] = Q_i . K_j,  j = j0 + nt*16 + g*4 + r
@@ -238,7 +236,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
-    if (PF && jt + 1 < nkt) load_tile(jt + 1, R);  // next tile in flight during the gather / softmax / P.V phase
+    if (PF) load_tile(min(jt + 1, nkt - 1), R);  // next tile in flight during the gather / softmax / P.V phase (unconditional: behind a
+                                                 // branch the compiler cannot count the requests and later waits cover them)
 
     // ---- (3) gather the bias terms, online softmax.  No clamps: in-range (i, j) always land inside the sub-windows;
     // padding queries read finite-or-not garbage that stays in their own lane column and is dropped at the end,
@@ -435,27 +434,34 @@ extern "C" int fbl_disent_attn_fwd(const void* q, int64_t ldq, const void* k, in
   const int smem_bytes = sm_total(Sp);
   // three workgroups per CU (<= 168 VGPRs), no register prefetch of the next key tile: the other two workgroups of the CU
   // cover the load (measured 88.6 us vs 97.2 with the prefetch, whose registers spill)
+  static const int pf = FBL_ENV_INT("FBL_ATTN_PF", 1);  // (measurement builds) register prefetch of the next key tile
   static int attr_bytes = 0;
   if (smem_bytes > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_fwd_kernel<3, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[8] = {(const void*)attn_fwd_kernel<3, false>, (const void*)attn_fwd_kernel<3, false, true>,
+                          (const void*)attn_fwd_kernel<3, false, false, true>, (const void*)attn_fwd_kernel<3, false, true, true>,
+                          (const void*)attn_fwd_kernel<3, true>, (const void*)attn_fwd_kernel<3, true, true>,
+                          (const void*)attn_fwd_kernel<3, true, false, true>, (const void*)attn_fwd_kernel<3, true, true, true>};
+    for (int f = 0; f < 8; ++f) {
+      hipError_t e = hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_bytes = smem_bytes;
   }
   dim3 grid((unsigned)((S + 63) / 64) * nh * B);
-  if (row0 && psave)
-    hipLaunchKernelGGL((attn_fwd_kernel<3, false, true, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
-  else if (row0)
-    hipLaunchKernelGGL((attn_fwd_kernel<3, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
-  else if (psave)
-    hipLaunchKernelGGL((attn_fwd_kernel<3, false, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<3, false>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);
+#define FBL_FWD_LAUNCH(PF_)                                                                                             \
+  do {                                                                                                                  \
+    if (row0 && psave)                                                                                                  \
+      hipLaunchKernelGGL((attn_fwd_kernel<3, PF_, true, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);   \
+    else if (row0)                                                                                                      \
+      hipLaunchKernelGGL((attn_fwd_kernel<3, PF_, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);         \
+    else if (psave)                                                                                                     \
+      hipLaunchKernelGGL((attn_fwd_kernel<3, PF_, false, true>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);  \
+    else                                                                                                                \
+      hipLaunchKernelGGL((attn_fwd_kernel<3, PF_>), grid, dim3(256), smem_bytes, (hipStream_t)stream, a);               \
+  } while (0)
+  if (pf) FBL_FWD_LAUNCH(true);
+  else FBL_FWD_LAUNCH(false);
+#undef FBL_FWD_LAUNCH
   FBL_CHECK_LAUNCH();
   return 0;
 }
