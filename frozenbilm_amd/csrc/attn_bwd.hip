@@ -686,19 +686,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dsp_kernel(BwdPArgs a) {
 //    table: twelve 16-byte loads per lane and pair in 64-byte segments, three times the bytes, 20 of the kernel's 110 us) and
 //    the A fragments are transposing LDS reads.  A wave's keys reach 96 of the 128 deltas of a pair: 3 k-steps x 4 MFMAs.
 // dS / dS^T are still written (fbl_attn_pos_grad and the query-major pass read them).
+// Swizzle of the [64 rows][8 x 16 B] images whose MFMA fragments are eight CONSECUTIVE rows of one column (natural k order:
+// transposing reads of rows g*8 + {0..3} and + 4): the 32 lanes of a read pass touch rows {0..3} and {8..11} (+16 k), so the
+// chunk index is XOR-ed with (row & 3) | (bit 3 of the row) << 2 -- with the usual row & 7 rows r and r + 8 collide (2-way on
+// every read: 30 % of the LDS cycles of the first version of these kernels).
+__device__ __forceinline__ int tswz(int r) { return (r & 3) | ((r >> 1) & 4); }
+
 struct BwdPKArgs {
   BwdPArgs p;
   const bf16* q; long ldq;   // row-major like v, head h at column h*64
   const bf16* pqx;           // [nh][2 Sp][64]
   bf16* dK; long lddk;
 };
-constexpr int LDG2 = 136;                    // bf16 row stride of the sheared tile (128 used)
+constexpr int LDG2 = 144;                    // bf16 row stride of the sheared tile (128 used; 72 dwords: conflict-free b128 reads and 16-bit stores)
 constexpr int K_DOS = 0;                     // [64 i][64] bf16 swizzled
 constexpr int K_QS = K_DOS + 8192;           // [64 i][64] bf16 swizzled
 constexpr int K_PS = K_QS + 8192;            // [64 i][LDP] bf16: P~, then (same columns per wave) the dS staging tile
 constexpr int K_STT = K_PS + 64 * LDP * 2;   // dS^T staging [64 j][LDV]
 constexpr int K_G2 = K_STT + 64 * LDV * 2;   // sheared dS^T [64 j][LDG2]
-constexpr int K_TAB = K_G2 + 64 * LDG2 * 2;  // two [64 t][64] bf16 blocks of PQX, swizzled like the Q tile: block beta in slot beta & 1
+constexpr int K_TAB = K_G2 + 64 * LDG2 * 2;  // two [64 t][64] bf16 blocks of PQX, chunk ^= tswz(row): block beta in slot beta & 1
 constexpr int K_ROW = K_TAB + 16384;         // float f[64], D[64]
 constexpr int K_TOTAL = K_ROW + 512;
 static_assert(2 * K_TOTAL <= 160 * 1024, "two workgroups per CU");
@@ -736,6 +742,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
   const int fb0 = c * 128 + ((g ^ (c & 7)) << 4), fb1 = fb0 ^ 64;  // dO fragment of row x*16 + c: + x*2048
   const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);           // dO / Q staging slot of row srow + 32 t: + t*4096
   const int sp = srow * (LDP * 2) + sch * 16;                      // P staging slot: + t*32*LDP*2
+  const int sbx = srow * 128 + ((sch ^ tswz(srow)) << 4);          // table staging slot of row srow + 32 t: + t*4096 (tswz(r + 32) = tswz(r))
 
   bf16x8 vf[2];
   {
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
     for (int t = 0; t < 2; ++t) {
       *(bf16x8*)(smem + K_DOS + sb + t * 4096) = R.d[t];
       *(bf16x8*)(smem + K_QS + sb + t * 4096) = R.q[t];
-      *(bf16x8*)(smem + K_TAB + (((it_i0 >> 6) + beta0 + 1) & 1) * 8192 + sb + t * 4096) = R.x[t];
+      *(bf16x8*)(smem + K_TAB + (((it_i0 >> 6) + beta0 + 1) & 1) * 8192 + sbx + t * 4096) = R.x[t];
       *(bf16x8*)(smem + K_PS + sp + t * (32 * LDP * 2)) = R.p[t];
     }
     if (tid < 64) {  // padding and masked queries: lse = +inf in the forward -> P = 0
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
     load_q(0, R);
 #pragma unroll
     for (int t = 0; t < 2; ++t)  // block beta0 (pair 0's first one)
-      *(bf16x8*)(smem + K_TAB + (beta0 & 1) * 8192 + sb + t * 4096) =
+      *(bf16x8*)(smem + K_TAB + (beta0 & 1) * 8192 + sbx + t * 4096) =
           buf_ld16(xr, (uint32_t)((srow + t * 32) * 128 + sch * 16), (uint32_t)(beta0 * 8192));
   }
   for (int it = 0; it < nqt; ++it) {
@@ -912,8 +919,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
         for (int dt = 0; dt < 4; ++dt) {
           const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
           union { tr16x4 h[2]; bf16x8 v; } ut;
-          ut.h[0] = lds_tr16((const bf16*)(smem + K_TAB + slot + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
-          ut.h[1] = lds_tr16((const bf16*)(smem + K_TAB + slot + (r + 4) * 128 + ((ch ^ ((r + 4) & 7)) << 4) + sub));
+          ut.h[0] = lds_tr16((const bf16*)(smem + K_TAB + slot + r * 128 + ((ch ^ tswz(r)) << 4) + sub));
+          ut.h[1] = lds_tr16((const bf16*)(smem + K_TAB + slot + (r + 4) * 128 + ((ch ^ tswz(r + 4)) << 4) + sub));
           dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ut.v, gf, dk[dt], 0, 0, 0);
         }
       }
@@ -979,7 +986,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdQArgs a) {
   const int kl = a.klen ? min(a.klen[b], S) : S;
   const int nkt = (i0 < kl) ? (kl + 63) / 64 : 0;  // rows beyond the last valid position: dS = 0 (never written) -> dQ = 0
   const int srow = tid >> 3, sch = tid & 7;
-  const int sb = srow * 128 + ((sch ^ (srow & 7)) << 4);  // K / table staging slot of row srow + 32 t: + t*4096
+  const int sb = srow * 128 + ((sch ^ tswz(srow)) << 4);  // K / table staging slot of row srow + 32 t: + t*4096 (tswz(r + 32) = tswz(r))
   const int ks0 = (w < 2) ? 0 : 1;  // this wave's rows reach x in [16 w + 1, 16 w + 79]: three of the four 32-wide k-steps
   bf16* g1 = (bf16*)(smem + Q_G1) + (w * 16 + c) * LDG1;  // this lane's row of the sheared tile (column x - 32*ks0)
   const int wr = w * 16 + c;                              // its row of the tile
@@ -1043,8 +1050,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdQArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
         union { tr16x4 h[2]; bf16x8 v; } u;
-        u.h[0] = lds_tr16((const bf16*)(smem + Q_KS + rk * 128 + ((ch ^ (rk & 7)) << 4) + sub));
-        u.h[1] = lds_tr16((const bf16*)(smem + Q_KS + (rk + 4) * 128 + ((ch ^ ((rk + 4) & 7)) << 4) + sub));
+        u.h[0] = lds_tr16((const bf16*)(smem + Q_KS + rk * 128 + ((ch ^ tswz(rk)) << 4) + sub));
+        u.h[1] = lds_tr16((const bf16*)(smem + Q_KS + (rk + 4) * 128 + ((ch ^ tswz(rk + 4)) << 4) + sub));
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, sf, dq[dt], 0, 0, 0);
       }
     }
@@ -1059,8 +1066,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdQArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         const int ch = dt * 2 + ((c >> 1) & 1), sub = (c & 1) * 8;
         union { tr16x4 h[2]; bf16x8 v; } ut;
-        ut.h[0] = lds_tr16((const bf16*)(smem + Q_TAB + slot + r * 128 + ((ch ^ (r & 7)) << 4) + sub));
-        ut.h[1] = lds_tr16((const bf16*)(smem + Q_TAB + slot + (r + 4) * 128 + ((ch ^ ((r + 4) & 7)) << 4) + sub));
+        ut.h[0] = lds_tr16((const bf16*)(smem + Q_TAB + slot + r * 128 + ((ch ^ tswz(r)) << 4) + sub));
+        ut.h[1] = lds_tr16((const bf16*)(smem + Q_TAB + slot + (r + 4) * 128 + ((ch ^ tswz(r + 4)) << 4) + sub));
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ut.v, gf, dq[dt], 0, 0, 0);
       }
     }
