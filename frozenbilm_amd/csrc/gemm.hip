@@ -739,6 +739,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     auto kfn = gemm_bf16_nt_kernel<4, FBL_ACT_NONE, FBL_AUX_NONE, true, 0, 4, true>;
     constexpr int smem_bytes = KSKIP_SMEM_BYTES > TileCfg<4>::SMEM_BYTES ? KSKIP_SMEM_BYTES : TileCfg<4>::SMEM_BYTES;
     if (N > 64 || (K / BK + splitk - 1) / splitk > KSKIP_MAX_STEPS) return FBL_ERR_SHAPE;  // (64 B rows staged, LDS list of valid K-steps)
+    if (K / BK >= 32768) return FBL_ERR_SHAPE;  // the list holds ABSOLUTE k-step indices as int16
     if (!attr_ks) {
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
       if (e != hipSuccess) return (int)e;

@@ -54,6 +54,7 @@ class LossLog:
         self.run, self.name, self.stop, self.delayed = run, name, stop_on_nonfinite, delayed
         self.reducer = reducer if (reducer is not None and getattr(reducer, "carries_scalars", False)) else None
         self.pending = None
+        self._staged_loss = None
         self._host = None
         self._flip = 0
         run.loss_log = self
@@ -95,6 +96,7 @@ class LossLog:
             return
         if self.reducer is not None and dist.get_world_size() > 1:
             self.reducer.stage_scalars(loss.reshape(1))  # leaves with the first gradient bucket of this step's backward
+            self._staged_loss = loss.detach()
             self.pending = ("reducer", [self.name])
             return
         reduced = dist.reduce_dict({self.name: loss})
@@ -110,7 +112,15 @@ class LossLog:
         pend, self.pending = self.pending, None
         if pend[0] == "reducer":
             vals = self.reducer.take_scalars()
-            if vals is None:  # (no backward ran for this loss: nothing was exchanged)
+            if vals is None:
+                # No collective of this step carried the staged loss (a backward that did not go through the engine's reducer,
+                # or a reducer still held): the stop-before-update guarantee must not depend on that -- reduce and read the
+                # loss now, like the path without a reducer (main.py:73-78 checks the loss before every update).
+                loss = self._staged_loss
+                if loss is None:
+                    return
+                reduced = dist.reduce_dict({self.name: loss})
+                self._emit({k: float(v.item()) for k, v in reduced.items()})
                 return
             self._emit(dict(zip(pend[1], vals)))
             return

@@ -464,6 +464,11 @@ class DebertaV2ForMaskedLM(nn.Module):
             if logits is not None:
                 out = MaskedLMOutput(loss=None, logits=logits, hidden_states=None, attentions=None)
                 return out if return_dict is not False else (logits,)
+        if (not self.training_graphs and eng.reducer is not None and "_overlap_before_graphs" in eng.reducer.__dict__
+                and not self.__dict__.get("_train_graphs_auto_off")):
+            from ..train_graph import restore_reducer_overlap
+
+            restore_reducer_overlap(eng)  # graphs were on earlier in this run: give the reducer its overlap placement back
         if (self.training_graphs and not self.packed_rows and self.training and labels is not None and not output_hidden_states
                 and not output_attentions
                 and logit_rows is None and not (self.n_ans and not mlm) and torch.is_grad_enabled()):

@@ -134,6 +134,16 @@ class GraphedStep:
             eng.reducer.finish()
 
 
+def restore_reducer_overlap(eng):
+    """The CALLER switched `model.training_graphs` off again (on every rank, like any other change of the training loop): the
+    reducer goes back to the overlap placement it had before the graphs forced "after" mode -- otherwise the data-parallel
+    overlap stays lost for the rest of the run.  Not used when the feature switched ITSELF off on this rank (capture budget)."""
+    red = getattr(eng, "reducer", None)
+    prev = None if red is None else red.__dict__.pop("_overlap_before_graphs", None)
+    if prev is not None:
+        red.overlap = prev
+
+
 def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, labels):
     """`model.forward` of a training step through the captured graphs (captured on first use of a shape).  Returns the loss
     (connected to the trainable parameters for `.backward()`) and the Run (for `logits` on demand), or None when this call
@@ -144,6 +154,7 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
     # falls back to the eager step (no labelled row in its shard, a failed capture) must issue the same pattern, or the ranks'
     # collectives no longer match in count and size.  While training_graphs is on the reducer therefore runs in "after" mode.
     if eng.reducer is not None and eng.reducer.overlap != "after":
+        eng.reducer.__dict__.setdefault("_overlap_before_graphs", eng.reducer.overlap)  # restored by restore_reducer_overlap()
         eng.reducer.overlap = "after"
     dev = eng.dev
     if attention_mask is None:
@@ -181,7 +192,13 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
             del cache[next(iter(cache))]
         # a loop whose batch shapes keep changing (text padded to the longest sample, label counts crossing a row bucket) would
         # capture -- one eager warm-up step plus two captures, ~10 GB of pooled activations each -- and evict continuously
-        n_cap = model.__dict__.get("_train_graph_captures", 0) + 1
+        # (counted: DISTINCT configurations of the current engine -- a rebuilt engine (load_state_dict, .to(), new answer
+        #  embeddings) or a cache the caller cleared starts over, and re-capturing a configuration seen before does not count)
+        seen = model.__dict__.setdefault("_train_graph_keys", (id(eng), set()))
+        if seen[0] != id(eng):
+            seen = model.__dict__["_train_graph_keys"] = (id(eng), set())
+        seen[1].add(key[1:])
+        n_cap = len(seen[1])
         model.__dict__["_train_graph_captures"] = n_cap
         if n_cap > MAX_CAPTURES:
             import warnings
@@ -189,6 +206,9 @@ def graphed_forward(model, eng, input_ids, attention_mask, video, video_mask, la
             warnings.warn(f"model.training_graphs: {n_cap} distinct (batch shape, label capacity) configurations seen -- the loop "
                           "is not shape-static (pad the text to a fixed length / bucket it); staying on the eager path")
             model.training_graphs = False
+            # (the reducer STAYS in "after" mode: the other ranks may still be served by their graphs -- row capacities differ per
+            #  rank, so the budgets run out at different steps -- and every rank must keep issuing the same one collective)
+            model.__dict__["_train_graphs_auto_off"] = True
             cache.clear()
             return None
         # one eager step of this shape first: lazy initialisations (kernel attributes, workspaces, allocator warm-up) happen

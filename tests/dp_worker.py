@@ -43,6 +43,16 @@ def main():
     m.to(dev)
     if config == "tiny+packed":  # model.packed_rows: every rank packs its own ragged shard (different row counts per rank)
         m.packed_rows = True
+    if config == "tiny+graphs_mixed":
+        # model.training_graphs on both ranks, but rank 1's capture budget is already used up: it switches the feature off by
+        # itself and serves every step eagerly while rank 0 replays its graphs -- the two must keep issuing the SAME collectives
+        # (one [0, n) all-reduce per step: the reducer stays in "after" mode on the rank that fell back)
+        import frozenbilm_amd.train_graph as TG
+
+        m.train()  # (dropout live: this configuration only compares the ranks with each other)
+        m.training_graphs = True
+        if rank == 1:
+            TG.MAX_CAPTURES = 0
     # small buckets: several collectives in flight during backward; argv[2] = where they are launched (GradReducer.overlap)
     red = GradReducer.attach(m, min_bucket_elems=1 << 10, overlap=sys.argv[2] if len(sys.argv) > 2 else None)
     per = 2
@@ -57,6 +67,17 @@ def main():
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
     n_coll = len(red.last_launched)
+    pattern_same = True
+    if config == "tiny+graphs_mixed":
+        # both ranks: one collective over the whole flat buffer per step, whichever way the step was served
+        mine_pat = torch.tensor([len(red.last_launched), red.last_launched[0][0], red.last_launched[-1][1], red.n_collectives],
+                                dtype=torch.int64, device=dev)
+        both = [torch.zeros_like(mine_pat) for _ in range(world)]
+        dist.all_gather(both, mine_pat)
+        pattern_same = all(torch.equal(both[0], b_) for b_ in both) and int(mine_pat[0]) == 1
+        served = "graph" if m.__dict__.get("_train_graphs") else "eager"
+        print(f"[dp_worker] rank {rank}: served by {served}, collectives {both}", flush=True)
+        assert (served == "graph") == (rank == 0), served
     # a third step with the loops' loss bookkeeping: the logged loss rides in front of the first gradient bucket (no collective
     # of its own), and the host reads the rank-averaged value between backward and the update (loops.LossLog.begin / check)
     from frozenbilm_amd.loops import LossLog
@@ -96,7 +117,7 @@ def main():
         torch.save({"grads": grads, "losses": losses, "backend": dist.get_backend(), "collectives": n_coll,
                     "rccl_ranks": red.rccl_ranks, "overlap": red.overlap, "covers": covers, "launch_order": list(red.last_launched),
                     "ranks_agree": bool(ok.item() == 1.0), "world": world, "loss_rides": bool(loss_rides),
-                    "extra_collectives_for_the_loss": int(extra)}, sys.argv[1])
+                    "extra_collectives_for_the_loss": int(extra), "pattern_same": bool(pattern_same)}, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()
 

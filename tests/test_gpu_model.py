@@ -1030,6 +1030,15 @@ def test_two_rank_data_parallel_with_packed_rows(tmp_path):
     assert worst < 1e-5, worst
 
 
+def test_two_rank_graph_replay_beside_an_eager_rank(tmp_path):
+    """model.training_graphs on both ranks, rank 1 falls back to the eager step (its capture budget is used up): the ranks must
+    issue identical collectives -- one all-reduce over the whole flat buffer per step (rank-divergent collective
+    patterns) -- and end with the same reduced gradients."""
+    got = _run_two_ranks(tmp_path, "attention_windows", "tiny+graphs_mixed")
+    assert got["ranks_agree"] and got["world"] == 2 and got["covers"] and got["pattern_same"], got
+    assert got["collectives"] == 1 and got["overlap"] == "after", got
+
+
 @pytest.mark.slow
 def test_two_rank_data_parallel_at_xlarge_dimensions(tmp_path):
     """The same check at the true xlarge dimensions (H = 1536, 24 heads, I = 6144, 192-wide adapters; 4 layers, B = 2 per
