@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_ds_kernel(BwdAArgs a) {
 // not repeat Q.K^T, the two bias GEMMs against the position-table windows and the LDS gather (kernel A above: 28 of its 44
 // MFMA pairs, ten fp16 tile stores, 32 element reads per lane and a barrier per tile pair; 288 GB of HBM hold the 157 MB
 // per layer execution easily):  P_ij = psave_ij * exp2(msave_i - lse_i*log2(e)).  Everything after P is kernel A's:
-// dP = dO.V^T through the regenerated dropout mask, dS = P*(dP - D)*scale, dV += drop(P)^T.dO, dS and dS^T staged through
+// dP = dO.V^T through the dropout mask (the sign bits of psave), dS = P*(dP - D)*scale, dV += drop(P)^T.dO, dS and dS^T staged through
 // LDS.  Two barriers per tile pair, 37 KiB of LDS, no index table, no position tables.
 struct BwdPArgs {
   const bf16* psave; const float* msave;
@@ -607,19 +607,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dsp_kernel(BwdPArgs a) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + P_DOS + nt * 2048 + fb0), vf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + P_DOS + nt * 2048 + fb1), vf[1], acc, 0, 0, 0);
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f) {
+      // the forward left the dropout decision in the sign bit of the saved probability (P >= 0: set = dropped)
+      float keep[4];
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          uint32_t x, y;
-          attn_drop_block(dk, (i0 + nt * 16 + g * 4 + bb * 2) >> 1, j >> 1, Sp >> 1, &x, &y);
-          keep[bb * 2] = attn_drop_keep(dk, x, y, 0, j & 1);
-          keep[bb * 2 + 1] = attn_drop_keep(dk, x, y, 1, j & 1);
-        }
-      }
+      for (int r = 0; r < 4; ++r) keep[r] = pu.t[r] < 0 ? 0.f : dk.inv_keep;  // (the 16-bit pattern as a signed integer)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = f4[r] != 0.f ? bf2f(pu.v[r]) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
+        const float pv = f4[r] != 0.f ? fabsf(bf2f(pu.v[r])) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
         dsb[nt][r] = f2bf(pv * (acc[r] * keep[r] - d4[r]) * a.scale);
         pfh[nt][r] = f2bf(pv * keep[r]);
       }
@@ -849,19 +843,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dspk_kernel(BwdPKArgs ka) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + K_DOS + nt * 2048 + fb0), vf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(smem + K_DOS + nt * 2048 + fb1), vf[1], acc, 0, 0, 0);
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f) {
+      // the forward left the dropout decision in the sign bit of the saved probability (P >= 0: set = dropped)
+      float keep[4];
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          uint32_t x, y;
-          attn_drop_block(dkey, (i0 + nt * 16 + g * 4 + bb * 2) >> 1, j >> 1, Sp >> 1, &x, &y);
-          keep[bb * 2] = attn_drop_keep(dkey, x, y, 0, j & 1);
-          keep[bb * 2 + 1] = attn_drop_keep(dkey, x, y, 1, j & 1);
-        }
-      }
+      for (int r = 0; r < 4; ++r) keep[r] = pu.t[r] < 0 ? 0.f : dkey.inv_keep;  // (the 16-bit pattern as a signed integer)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = f4[r] != 0.f ? bf2f(pu.v[r]) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
+        const float pv = f4[r] != 0.f ? fabsf(bf2f(pu.v[r])) * f4[r] : 0.f;  // (f = 0 rows may hold garbage in psave)
         dsb[nt][r] = f2bf(pv * (acc[r] * keep[r] - d4[r]) * a.scale);
         pfh[nt][r] = f2bf(pv * keep[r]);
       }

@@ -40,7 +40,7 @@ struct AttnArgs {
   const int32_t* row0;  // [B+1] packed-row layout (PACKED kernels): sample b owns activation rows [row0[b], row0[b+1]) =
                         // its positions 0 .. row0[b+1]-row0[b]-1; null = the padded [B, S] grid (row b*S + s)
   // SAVEP kernels (training): what the backward would otherwise recompute -- psave[b,h,i,j] = exp2(k2*(s_ij - m)) (bf16,
-  // [B,nh,Sp,Sp], BEFORE dropout) with m the running row maximum at key tile j/64, and msave[b,h,j/64,i] = k2*m (fp32,
+  // [B,nh,Sp,Sp], BEFORE dropout, sign bit set where dropout dropped the pair) with m the running row maximum at key tile j/64, and msave[b,h,j/64,i] = k2*m (fp32,
   // [B,nh,Sp/64,S]): P_ij = psave * exp2(msave - lse*log2(e)).  Only the tile pairs the forward visits are written.
   bf16* psave;
   float* msave;
@@ -299,17 +299,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    if constexpr (SAVEP) {
-      // the un-normalised probabilities of this pair leave as they are (4 consecutive keys = 8 bytes per lane and key group;
-      // padding query rows i < Sp exist in the buffer and may receive garbage: their lse is +inf, the backward reads P = 0)
-      bf16* pp = a.psave + (((long)b * a.nh + h) * Sp + i) * Sp + j0 + g * 4;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        *(bf16x4*)(pp + nt * 16) = (bf16x4){f2bf(p[nt * 4]), f2bf(p[nt * 4 + 1]), f2bf(p[nt * 4 + 2]), f2bf(p[nt * 4 + 3])};
-      if (g == 0 && i < S) a.msave[(((long)b * a.nh + h) * (Sp >> 6) + jt) * S + i] = m_new * k2;
-    }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    float kf[16];  // dropout keep factors (0 or 1/(1-p))
+#pragma unroll
+    for (int e = 0; e < 16; ++e) kf[e] = 1.f;
     if (a.p_drop > 0.f && !ATTN_DBG(8)) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -317,10 +311,27 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(AttnArgs a) {
         for (int bb = 0; bb < 2; ++bb) {
           uint32_t x, y;
           attn_drop_block(dk, i >> 1, (j0 + nt * 16 + g * 4 + bb * 2) >> 1, Sp >> 1, &x, &y);
-          p[nt * 4 + bb * 2] *= attn_drop_keep(dk, x, y, i & 1, 0);
-          p[nt * 4 + bb * 2 + 1] *= attn_drop_keep(dk, x, y, i & 1, 1);
+          kf[nt * 4 + bb * 2] = attn_drop_keep(dk, x, y, i & 1, 0);
+          kf[nt * 4 + bb * 2 + 1] = attn_drop_keep(dk, x, y, i & 1, 1);
         }
     }
+    if constexpr (SAVEP) {
+      // the un-normalised probabilities of this pair leave as they are, BEFORE dropout, with the dropout decision in the sign
+      // bit (P >= 0: a set sign = dropped) -- the backward then neither recomputes the scores nor regenerates the mask (4
+      // consecutive keys = 8 bytes per lane and key group; padding query rows i < Sp exist in the buffer and may receive
+      // garbage: their lse is +inf, the backward reads P = 0)
+      bf16* pp = a.psave + (((long)b * a.nh + h) * Sp + i) * Sp + j0 + g * 4;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bf16x4 v4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = f2bf(kf[nt * 4 + r] == 0.f ? -p[nt * 4 + r] : p[nt * 4 + r]);
+        *(bf16x4*)(pp + nt * 16) = v4;
+      }
+      if (g == 0 && i < S) a.msave[(((long)b * a.nh + h) * (Sp >> 6) + jt) * S + i] = m_new * k2;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[e] *= kf[e];
     // ---- (4) O^T += V^T . P^T ; k-slot e of step kk  <->  key kk*32 + (e>>2)*16 + g*4 + (e&3)
     if (!ATTN_DBG(4))
 #pragma unroll

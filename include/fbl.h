@@ -251,7 +251,8 @@ int fbl_head_transpose(const void* v_bf16, int64_t ldv, void* vt_bf16, int B, in
  *   (fbl_attn_bwd_prep: q / k / dO / O; fbl_disent_attn_bwd_ds: q / k / v / dO / dV; fbl_disent_attn_bwd_shear: out).
  *   psave / msave (optional, both or neither; training): the forward also leaves what the backward would otherwise
  *   recompute -- psave bf16 [B,nh,Sp,Sp]: psave[b,h,i,j] = exp2(k2*(s_ij - m)) with s the unscaled score, k2 = scale*log2(e)
- *   and m the running row maximum when key tile j/64 was processed (BEFORE dropout; exactly 0 for masked keys); msave fp32
+ *   and m the running row maximum when key tile j/64 was processed (BEFORE dropout, exactly 0 for masked keys; the SIGN BIT
+ *   carries the dropout decision of the pair: set = dropped, so the backward does not regenerate the mask); msave fp32
  *   [B,nh,Sp/64,S]: msave[b,h,j/64,i] = k2*m.  P_ij = psave_ij * exp2(msave - lse_i*log2(e)).  Only the tile pairs the forward
  *   visits (both tile indices below ceil(klen/64)) are written -- fbl_disent_attn_bwd_dsp reads exactly those.
  * ref: model/deberta.py:717-818 (forward), :820-947 (disentangled_attention_bias), :100-138 (XSoftmax). */
@@ -321,8 +322,9 @@ int fbl_disent_attn_bwd_ds(const void* q, const void* k, const void* v, int64_t 
                            const int32_t* border, const float* lse, const float* Dv,
                            float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* dV, int64_t lddv, void* dS, void* dST, int B,
                            int S, int Sp, int nh, int span2, int lin_span, const int32_t* row0, void* stream);
-/* fbl_disent_attn_bwd_ds without the recomputation: P comes from the psave / msave a training forward left (see
- * fbl_disent_attn_fwd); same outputs (dV, dS, dS^T), same dropout mask (seed), q / k / position tables not needed.
+/* fbl_disent_attn_bwd_ds without the recomputation: P and the dropout mask come from the psave / msave a training forward left
+ * (see fbl_disent_attn_fwd; p_drop gives the scale of the kept pairs, the seed arguments are not read); same outputs (dV, dS,
+ * dS^T), q / k / position tables not needed.
  * ref: autograd of model/deberta.py:789-818 (softmax, dropout, context), XSoftmax.backward :134-138, XDropout.backward :185-190. */
 int fbl_disent_attn_bwd_dsp(const void* psave, const float* msave, const void* v, int64_t ldv, const void* dO, int64_t ldo,
                             const int32_t* klen, const int32_t* border, const float* lse, const float* Dv, float scale,
