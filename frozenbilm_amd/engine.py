@@ -1163,7 +1163,7 @@ class Engine:
         dqkv = torch.empty(N, 3 * H, dtype=BF16, device=self.dev)
         from .attn_bwd import disent_attn_bwd
 
-        if self.reducer is not None:  # ~0.35 ms without one-workgroup-per-CU GEMM tiles: where gradient collectives may start
+        if self.reducer is not None:  # ~0.15 ms (0.35 until round 6) without one-workgroup-per-CU GEMM tiles: where gradient collectives may start
             self.reducer.window()
 
         # The position-table products of this execution (dPK = G1^T.Q, dPQ = G2^T.K) are NOT formed here: the shear passes and
