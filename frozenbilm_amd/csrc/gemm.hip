@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmTnArgs g) {
 
 // 256x256 (or 224x256) tiles only where both dimensions fill them and the grid still covers half the chip
 static inline bool big_tile_shape(int M, int N, int batch) {
-  return batch == 1 && M >= 2048 && N >= 1024 && ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
+  // (M >= 512 with a very wide N: the vocabulary GEMM of the loss on the labelled rows, [~700 x 128100 x 1536] -- 3 x 501 big tiles)
+  static const int wide = FBL_ENV_INT("FBL_GEMM_WIDE", 1);
+  return batch == 1 && (M >= 2048 || (wide && M >= 512 && N >= 16384)) && N >= 1024 &&
+         ((long)((M + 255) / 256) * ((N + 255) / 256) >= 128);
 }
 
 constexpr double FBL_R128_US_PER_KTILE = 0.86;  // 128-row 8-phase tile: time per K-tile of one workgroup (measured: [5322,1536,6144] 88 us)

@@ -41,14 +41,15 @@ def close(got, ref, rtol, atol, name=""):
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 130, 128), (1000, 1536, 1536), (333, 192, 1536), (256, 4608, 192),
                                    (130, 6, 64), (4100, 2052, 128), (8512, 1536, 192), (4100, 3584, 128), (8512, 192, 1536),
                                    (2100, 70, 64), (4100, 3500, 256), (4100, 3584, 1536), (8512, 6144, 384), (8512, 1536, 384), (4100, 2052, 256),
-                                   (4100, 4608, 256), (4100, 4500, 192), (2500, 8192, 128), (8512, 6144, 1536)])
+                                   (4100, 4608, 256), (4100, 4500, 192), (2500, 8192, 128), (8512, 6144, 1536), (691, 16500, 256)])
 # the last four: more than one round of 256x256 tiles (skewed single launch / whole rounds + remainder rows), K = 4, 3, 2 and
 # 24 K-tiles (3 and 2: below the 8-phase kernel's shortest pipeline -> 2-stage 256x256 tiles), ragged last tile column / row;
 # (4100,35xx,K>=256): the 8-phase 256x256 kernel (gemm8.hip; K = 256 is its shortest pipeline, N = 3500 a ragged last column
 # tile); (8512,6144): 8-phase tiles for the whole rounds + 64x128 tiles for the remaining rows (helper stream); (8512,1536,384) and
 # (4100,2052,256): 224-row 8-phase tiles (second wave row with three 16-row MFMA tiles per half);
 # (4100,2052) and (8512,1536): 224x256 tiles (fewer rounds x area); (4100,3584): 256x256 tiles (238 tiles, one round);
-# (8512,192) and (2100,70): 64x128 tiles (tall and narrow: the 128x128 grid would not cover the chip)
+# (8512,192) and (2100,70): 64x128 tiles (tall and narrow: the 128x128 grid would not cover the chip);
+# (691,16500): a few hundred rows against a very wide N -- the vocabulary GEMM of the loss on the labelled rows -- on 8-phase tiles
 def test_gemm_plain_bias(L, M, N, K):
     A, B = bf(rnd(M, K, seed=1)).to(BF16), bf(rnd(N, K, seed=2, scale=0.05)).to(BF16)
     bias = rnd(N, seed=3)

@@ -28,7 +28,9 @@ EDGE = [(4100, 3500, 256, "f32+bf16"), (4100, 3584, 384, "gelugrad"), (8512, 614
 PACKED = [(5834, 4608, 1536, "bf16"), (5322, 1728, 1536, "bf16"), (5322, 6144, 1536, "gelugrad"), (5322, 1728, 6144, "bf16"),
           (5322, 6144, 1536, "mulbf16"), (5322, 1536, 6144, "addf32"), (5322, 1536, 4608, "addf32"), (5322, 1536, 1792, "bf16"),
           (4100, 1536, 6144, "addf32"), (6900, 1536, 6144, "addf32"), (3000, 1536, 6144, "addf32")]
-shapes = {"hot": SQUARE + HOT, "square": SQUARE, "all": SQUARE + HOT + EDGE, "edge": EDGE, "packed": PACKED}[args.set]
+# the vocabulary GEMM of the loss on the labelled rows only (a few hundred to ~1300 rows at the bench batch)
+HEAD = [(691, 128100, 1536, "logits"), (768, 128100, 1536, "logits"), (1280, 128100, 1536, "logits")]
+shapes = {"head": HEAD, "hot": SQUARE + HOT, "square": SQUARE, "all": SQUARE + HOT + EDGE, "edge": EDGE, "packed": PACKED}[args.set]
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FBL_"))
 print(f"# {tag or 'default switches'}", flush=True)
 for M, N, K, var in shapes:
