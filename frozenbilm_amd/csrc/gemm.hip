@@ -508,6 +508,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
   g.out_f32 = out_f32; g.out_bf16 = (bf16*)out_bf16; g.out_pre = (bf16*)out_pre_bf16; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sAux = strideAux; g.sBias = strideBias;
   g.splitk = splitk;
+  g.k8_per = 0;
   g.ws = accumulate ? splitk_ws : nullptr;
   g.Nw = Nw;
   g.a_kblk = a_kblock_stride;
@@ -737,7 +738,39 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     FBL_CHECK_LAUNCH();
     return 0;
   }
-  if (accumulate && kskip_len) {
+  // Few rows against a very long K with a workspace at hand (the prediction head's backward dh = dlogits . E: [~700 x 1536 x
+  // 128128]): 8-phase 256 x 256 tiles, K cut into as many slices as fill the chip (18 tiles x 14 slices), partial tiles folded by
+  // splitk_reduce_kernel as below -- 463 -> ~235 us.  FBL_GEMM8_SK (measurement builds): 0 = the 128 x 128 two-stage kernel.
+  static const int sk8_on = FBL_ENV_INT("FBL_GEMM8_SK", 1);
+  bool done = false;
+  if (accumulate && sk8_on && g.ws && batch == 1 && !kskip_len && !a_kblock_stride && M >= 512 && N >= 1024 && (K / BK) % 2 == 0 &&
+      K / BK >= 128 && (long)M * lda * 2 < (1l << 32) && (long)N * ldb * 2 < (1l << 32)) {
+    const int nk = K / BK, tiles = ((M + 255) / 256) * ((N + 255) / 256), n_cu = device_cu_count();
+    int want = n_cu / tiles;
+    if (want >= 2) {
+      if (want > nk / 8) want = nk / 8;
+      int per = (nk + want - 1) / want;
+      per += per & 1;  // even
+      int s8 = (nk + per - 1) / per;
+      if (nk - (s8 - 1) * per < 4) {  // a last slice of 2 K-tiles is below the kernel's shortest pipeline
+        per += 2;
+        s8 = (nk + per - 1) / per;
+      }
+      if (s8 >= 2 && per >= 8 && nk - (s8 - 1) * per >= 4 && (int64_t)s8 * M * Nw <= splitk_ws_floats) {
+        GemmArgs g8 = g;
+        g8.splitk = s8;
+        g8.k8_per = per;
+        g8.tiles_m = (M + 255) / 256;
+        g8.tiles_n = (N + 255) / 256;
+        const int rc8 = launch_gemm8_splitk(g8, (hipStream_t)stream);
+        if (rc8) return rc8;
+        splitk = s8;
+        done = true;
+      }
+    }
+  }
+  if (done) {
+  } else if (accumulate && kskip_len) {
     static bool attr_ks = false;
     auto kfn = gemm_bf16_nt_kernel<4, FBL_ACT_NONE, FBL_AUX_NONE, true, 0, 4, true>;
     constexpr int smem_bytes = KSKIP_SMEM_BYTES > TileCfg<4>::SMEM_BYTES ? KSKIP_SMEM_BYTES : TileCfg<4>::SMEM_BYTES;

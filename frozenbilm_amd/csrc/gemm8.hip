@@ -59,7 +59,10 @@ constexpr int SMEM8_BYTES = (8 * 64 * 68 * 4 > RING_BYTES) ? 8 * 64 * 68 * 4 : R
 // 16-row MFMA tiles) for the M = 8512, N = 1536 GEMMs of the step: 38 x 6 = 228 tiles instead of 204 that are 14 % bigger.
 // RT = 2 (R128): 128-row tile (halves of 64 rows, BOTH wave rows own 32 of each = two MFMA tiles) for row counts at which
 // neither of the tall tiles covers the chip (packed ragged batches, small batches: M = 5322, N = 1536 -> 252 tiles).
-template <int ACT, int AUX, int VAR, int RT = 0>
+// SK: split-K -- blockIdx.y = slice ks of g.splitk: K-tiles [ks * k8_per, + k8_per) (the last slice: what is left), partial tile
+// stored to the workspace g.ws[ks] (folded by splitk_reduce_kernel): few rows against a very long K (the prediction head's
+// backward [~700 x 1536 x 128128]: 18 tiles x 14 slices instead of 72 tiles x 15 slices of the 128 x 128 two-stage kernel).
+template <int ACT, int AUX, int VAR, int RT = 0, bool SK = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   constexpr bool R224 = RT == 1, R128 = RT == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -73,7 +76,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
   constexpr int WROWS = R128 ? 32 : 64;                // rows of a half-tile that one wave row owns (the first one)
   constexpr int NRT = R128 ? 2 : 4;                    // its 16-row MFMA tiles
   const int m0 = tm * (2 * HROWS), n0 = tn * 256;
-  const int nk = g.K / BK;  // even, >= 4
+  const int ks = SK ? (int)blockIdx.y : 0;
+  const int kt0 = SK ? ks * g.k8_per : 0;
+  const int nk = SK ? min(g.K / BK - kt0, g.k8_per) : g.K / BK;  // even, >= 4
   const bool short_rows = R224 && wm == 1;  // this wave owns 3 (not 4) row tiles per half
 
   // ---- LDS-DMA source offsets (bytes from A / B, K-tile 0).  One instruction of the workgroup covers 64 rows of a
@@ -93,8 +98,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
       a_off[h][j] = (uint32_t)(((long)am * g.lda + lchunk * 8) * 2);
       b_off[h][j] = (uint32_t)(((long)bn * g.ldb + lchunk * 8) * 2);
     }
-  const char* Ab = (const char*)g.A;
-  const char* Bb = (const char*)g.B;
+  const char* Ab = (const char*)g.A + (long)kt0 * (BK * 2);
+  const char* Bb = (const char*)g.B + (long)kt0 * (BK * 2);
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
 
   // half-tile S (0 = A0, 1 = B0, 2 = B1, 3 = A1) of K-tile kt -> ring slot (BUF, S).  Scalar base + 32-bit lane offset
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     return;
   }
   const int ec = (lane & 15) * 4;
-  gemm_epilogue<ACT, AUX, false, 8, (VAR >> 3) & 3, R224, NRT>(g, smem, wave, lane, acc, m0 + wm * WROWS, HROWS,
-                                                               n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31), 0, 0,
-                                                               R128 ? 32 : (short_rows ? 48 : 64));
+  gemm_epilogue<ACT, AUX, SK, 8, (VAR >> 3) & 3, R224, NRT>(g, smem, wave, lane, acc, m0 + wm * WROWS, HROWS,
+                                                            n0 + (ec >> 5) * 128 + wn * 32 + (ec & 31), 0, ks,
+                                                            R128 ? 32 : (short_rows ? 48 : 64));
 }
 
 template <int ACT, int AUX, int RT>
@@ -298,6 +303,20 @@ int launch_variant(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+// split-K launch of the plain 256-row configuration: grid (tiles, slices)
+int launch_gemm8_splitk(const GemmArgs& g, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kfn = gemm8_kernel<FBL_ACT_NONE, FBL_AUX_NONE, 3, 0, true>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), SMEM8_BYTES, stream, g);
+  FBL_CHECK_LAUNCH();
+  return 0;
+}
 
 bool gemm8_eligible(const GemmArgs& g) {
   const int nk = g.K / BK;

@@ -28,6 +28,7 @@ struct GemmArgs {
   long ldc;
   long sA, sB, sC, sAux, sBias;  // batch strides in elements
   int splitk;
+  int k8_per;  // 8-phase kernel with splitk > 1: K-tiles per slice (even, >= 4; the last slice takes what is left, even too)
   int tiles_m, tiles_n;
   float* ws;  // split-K partials [batch][splitk][M][Nw] (Nw = N rounded up to 4) or null -> atomicAdd into out_f32
   int Nw;
@@ -447,6 +448,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, char* smem, int
 // instantiate (the caller then uses the 2-stage kernel).
 int launch_gemm8(const GemmArgs& g, int act, int aux_kind, int rows, dim3 grid, hipStream_t stream);  // rows: 256 / 224 / 128
 bool gemm8_eligible(const GemmArgs& g);
+int launch_gemm8_splitk(const GemmArgs& g, hipStream_t stream);  // plain 256-row tiles, g.splitk slices of g.k8_per K-tiles -> g.ws
 
 
 }  // namespace fblgemm

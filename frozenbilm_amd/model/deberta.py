@@ -412,8 +412,17 @@ class DebertaV2ForMaskedLM(nn.Module):
                 run_once()  # warm-up outside the capture (lazy initialisation, allocator)
                 torch.cuda.synchronize(eng.dev)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    logits = run_once()
+                import gc
+
+                gc_was_on = gc.isenabled()  # (no cyclic collection inside a capture: train_graph.TrainStep.capture)
+                gc.collect()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(graph):
+                        logits = run_once()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             except Exception as e:  # noqa: BLE001
                 import warnings
 

@@ -100,13 +100,25 @@ class GraphedStep:
     def capture(self):
         eng = self.eng
         red, eng.reducer = eng.reducer, None  # the gradient exchange stays outside the graphs (run_backward)
+        # The cyclic garbage collector must not run while a stream is capturing: an object it frees may own a HIP event (the
+        # events of an earlier pass's side-stream joins, a dropped engine's) and destroying an event during a capture aborts
+        # the process -- seen twice in round 6 as "Fatal Python error: Aborted ... Garbage-collecting" inside this function,
+        # with whatever allocation happened to cross the collector's threshold.  torch.cuda.graph collects on entry; nothing
+        # may collect until the capture has ended.
+        import gc
+
+        gc_was_on = gc.isenabled()
         try:
+            gc.collect()
+            gc.disable()
             with torch.cuda.graph(self.g_fwd, pool=self.pool):
                 self.run, self.loss_t = self._forward_launches()
             eng.attach_grads()
             with torch.cuda.graph(self.g_bwd, pool=self.pool):
                 eng.backward(self.run, self.gloss, attach=False)
         finally:
+            if gc_was_on:
+                gc.enable()
             eng.reducer = red
         return self
 

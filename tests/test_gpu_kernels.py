@@ -238,6 +238,18 @@ def test_gemm_splitk_accumulates_and_batched(L):
     for b in range(nb):
         close(out[:, 64 + b * Nb: 64 + (b + 1) * Nb], ref[b], 1e-4, 1e-3, f"batched {b}")
     assert (out[:, :64] == 0).all()
+    # few rows against a very long K with a workspace: 8-phase 256 x 256 tiles, K in slices that fill the chip (the prediction
+    # head's backward [~700 x 1536 x 128128]); ragged last row / column tile, accumulation into a pre-filled output, reproducible
+    for M, N, K in ((691, 1536, 64 * 260), (700, 1100, 64 * 130)):
+        A, B = bf(rnd(M, K, seed=7, scale=0.1)).to(BF16), bf(rnd(N, K, seed=8, scale=0.1)).to(BF16)
+        ws = torch.empty(24 << 20, dtype=F32, device=DEV)
+        out = torch.ones(M, N, dtype=F32, device=DEV)
+        L.gemm(A, B, out_f32=out, splitk=4, ws=ws)
+        ref = 1.0 + A.float() @ B.float().t()
+        close(out, ref, 1e-4, 2e-3 * ref.abs().max().item(), "8-phase split-K")
+        out2 = torch.ones(M, N, dtype=F32, device=DEV)
+        L.gemm(A, B, out_f32=out2, splitk=4, ws=ws)
+        assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("N,H,A,nad", [(8512, 1536, 192, 2), (333, 128, 16, 3), (1000, 200, 100, 1), (2100, 1536, 256, 16), (70, 64, 64, 2)])

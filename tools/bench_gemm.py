@@ -29,7 +29,8 @@ PACKED = [(5834, 4608, 1536, "bf16"), (5322, 1728, 1536, "bf16"), (5322, 6144, 1
           (5322, 6144, 1536, "mulbf16"), (5322, 1536, 6144, "addf32"), (5322, 1536, 4608, "addf32"), (5322, 1536, 1792, "bf16"),
           (4100, 1536, 6144, "addf32"), (6900, 1536, 6144, "addf32"), (3000, 1536, 6144, "addf32")]
 # the vocabulary GEMM of the loss on the labelled rows only (a few hundred to ~1300 rows at the bench batch)
-HEAD = [(691, 128100, 1536, "logits"), (768, 128100, 1536, "logits"), (1280, 128100, 1536, "logits")]
+HEAD = [(691, 128100, 1536, "logits"), (768, 128100, 1536, "logits"), (1280, 128100, 1536, "logits"),
+        (691, 1536, 128128, "splitk"), (1280, 1536, 128128, "splitk")]  # ... and of its backward dh = dlogits . E (split-K, accumulating)
 shapes = {"head": HEAD, "hot": SQUARE + HOT, "square": SQUARE, "all": SQUARE + HOT + EDGE, "edge": EDGE, "packed": PACKED}[args.set]
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FBL_"))
 print(f"# {tag or 'default switches'}", flush=True)
@@ -39,7 +40,8 @@ for M, N, K, var in shapes:
     B = (torch.rand(N, K, generator=g) * 2 - 1).to(dev).to(torch.bfloat16)
     ldc = (N + 63) // 64 * 64
     o16 = torch.empty(M, ldc, dtype=torch.bfloat16, device=dev) if var != "logits" else None
-    o32 = torch.empty(M, ldc, dtype=torch.float32, device=dev) if var in ("f32+bf16", "addf32", "logits") else None
+    o32 = torch.empty(M, ldc, dtype=torch.float32, device=dev) if var in ("f32+bf16", "addf32", "logits", "splitk") else None
+    if var == "splitk": o16 = None
     bias = torch.rand(N, device=dev)
     aux = None
     kw = dict(bias=bias, N=N)
@@ -52,6 +54,8 @@ for M, N, K, var in shapes:
         aux = torch.randn(M, ldc, device=dev).to(torch.bfloat16)
         kw.update(out_bf16=o16, aux=aux, aux_kind={"dgelu": L.AUX_MUL_DGELU_BF16, "mulbf16": L.AUX_MUL_BF16,
                                                     "addbf16": L.AUX_ADD_BF16}[var]); kw.pop("bias")
+    elif var == "splitk":
+        kw = dict(out_f32=o32, N=N, splitk=max(2, min(16, K // 8192)), ws=torch.empty(48 << 20, dtype=torch.float32, device=dev))
     elif var == "addf32":
         aux = torch.randn(M, ldc, device=dev)
         kw.update(out_f32=o32, aux=aux, aux_kind=L.AUX_ADD_F32); kw.pop("bias")
@@ -63,7 +67,7 @@ for M, N, K, var in shapes:
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / args.iters
     msg = ""
-    if args.check and var != "logits":
+    if args.check and var not in ("logits", "splitk"):
         base = A.float() @ B.float().t()
         if "bias" in kw: base = base + bias
         x = aux[:, :N].float() if aux is not None else None
