@@ -1,12 +1,14 @@
 """Host-side orchestration of the disentangled-attention backward (see csrc/attn_bwd.hip for the math).
 
-    prep     : D = rowdot(dO, O); K^T, Q^T (head-major [nh,64,B,Sp]); PK^T, PQ^T   (one launch)
-    kernel A : dV, dS, dS^T   (from the probabilities the training forward saved: fbl_disent_attn_bwd_dsp; recomputed
-               by fbl_disent_attn_bwd_ds when there are none -- engine_options["attn_save_p"] = False)
-    shear(0) : dQ = dS.K   + G1.PK                   shear(1) : dK = dS^T.Q + G2.PQ
-    pos_grad : dPK[h] = sum_b G1^T.Q , dPQ[h] = sum_b G2^T.K -- straight from dS / dS^T (fbl_attn_pos_grad: the sheared operand
-               G is formed on the fly out of LDS); engine_options["pos_grad_gt"] = True keeps the route of rounds 1-5 (the shear
-               passes write G^T, two split-K GEMMs per table contract it against Q^T / K^T)
+    prep     : D = rowdot(dO, O) + the position tables expanded by the index map (PQX / PKX)                       (one launch)
+    dspk     : dV, dK, dS, dS^T from the probabilities the training forward saved (fbl_disent_attn_bwd_dspk)
+    dq       : dQ = dS.K + the c2p term in Toeplitz form (fbl_disent_attn_bwd_dq)
+    pos_grad : dPK[h] = sum_b G1^T.Q , dPQ[h] = sum_b G2^T.K -- straight from dS / dS^T, all layer executions at the end of
+               backward (fbl_attn_pos_grad: the sheared operand G is formed on the fly out of LDS)
+Earlier routes behind engine options (A/B measurements; calls without saved probabilities): attn_save_p = False -> kernel A
+recomputes the probabilities (fbl_disent_attn_bwd_ds); attn_fused_dk / attn_toeplitz_dq = False -> the scatter-based shear
+passes of rounds 1-5 for dK / dQ (with K^T, Q^T, PK^T, PQ^T from the preparation kernel); pos_grad_gt = True -> the shear passes
+write G^T and two split-K GEMMs per table contract it against Q^T / K^T.
 """
 from __future__ import annotations
 

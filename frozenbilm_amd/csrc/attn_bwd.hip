@@ -8,14 +8,20 @@
 //   dK = dS^T.Q + G2.PQ,    G2[j,r] = sum_{i: idx(i-j)=r} dS[i,j]        (p2c)
 //   dPK = sum_b G1^T.Q ,  dPQ = sum_b G2^T.K     (per head; done by the GEMM kernel on G1^T/G2^T written here)
 //
-// Prep      (attn_bwd_prep): D = rowdot(dO, O) and the position-contiguous copies K^T, Q^T, PK^T, PQ^T, one launch.
-// Kernel A  (attn_bwd_ds):  one workgroup per (b, h, 64-key tile), sweeps the query tiles; recomputes P exactly like
-//            the forward (row-tile split fp16 T1/T2 bias GEMMs + LDS gather, same rounding) but with the KEYS as lane
-//            columns, so dV accumulates in registers; writes dS and dS^T (bf16, zero where masked) -- 2 x SxS bf16 per
-//            head is the only extra HBM.
-// Kernel BC (attn_bwd_shear<NEG>): one workgroup per (b, h, 32 rows): X_out = dSx.Y + G.Ptab with the scatter
-//            G[row, idx(+-(row-col))] += dSx[row,col] done by LDS stores / atomics into a [32 x W] bf16 tile, W =
-//            the index range the 32 rows can reach (~S+32 <= 512); also writes G^T for the position-table GEMMs.
+// The launches of one layer execution (round 6; frozenbilm_amd/attn_bwd.py):
+//   attn_bwd_prep  D = rowdot(dO, O) and the position tables expanded by the index map, PQX / PKX[h][delta + Sp][d] = table[idx(delta)]
+//                  (only what the chosen route needs: the transposed copies K^T, Q^T, PK^T, PQ^T of rounds 1-5 on request).
+//   attn_bwd_dspk  key-major: one workgroup per (b, h, 64-key tile) sweeps the query tiles; P from the probabilities the training
+//                  forward saved (dropout decision in their sign bit), dS, dV AND dK (dS^T.Q + the p2c term as a Toeplitz product of
+//                  a sheared LDS tile against PQX); writes dS and dS^T (bf16, zero where masked).
+//   attn_bwd_dq    query-major: reads dS, dQ = dS.K + the c2p term as a Toeplitz product against PKX.
+//   pos_grad       dPK / dPQ of ALL layer executions at the end of backward, straight from dS / dS^T (fbl_attn_pos_grad).
+// Earlier routes, kept behind engine options for A/B measurements and for calls without saved probabilities:
+//   attn_bwd_ds    kernel A that RECOMPUTES P exactly like the forward (row-tile split fp16 T1/T2 bias GEMMs + LDS gather, same
+//                  rounding) with the keys as lane columns; attn_bwd_dsp: kernel A from saved probabilities without dK.
+//   attn_bwd_shear<NEG> ("kernel BC"): one workgroup per (b, h, 32 rows): X_out = dSx.Y + G.Ptab with the scatter
+//                  G[row, idx(+-(row-col))] += dSx[row,col] done by LDS stores / atomics into a [32 x W] bf16 tile, W = the index
+//                  range the 32 rows can reach (~S+32 <= 512); optionally writes G^T for the position-table GEMMs of rounds 1-5.
 #include "attn_common.h"
 #include "../../include/fbl.h"
 
